@@ -1,0 +1,500 @@
+/*
+ * jv_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement (plain C99, scalar, single thread) of the reference's dense
+ * Jonker-Volgenant solvers, used only as the checker for the HIP path:
+ *   - tests/            compare the HIP results with it, bit for bit
+ *   - __graft_entry__.smoke()
+ *   - bench.py          "cpu_baseline" leg (kind "port")
+ * Nothing under gnn-accelerated-lap-warm-start-pipeline_amd/ may call it.
+ *
+ * Parity pin: this file is validated against (a) the reference's own sources
+ * compiled unmodified into oracle/_ref/ (see oracle/Makefile) on thousands of
+ * seeded cases (tests/test_oracle_vs_ref.py, run where /root/reference exists),
+ * (b) the golden vectors committed under tests/golden/ (generated from the
+ * reference by tests/golden/make_golden.py) and (c) the reference's known-answer
+ * cases in LAP/lap/tests/test_lapjv.py:60-129 (restated as data in
+ * tests/test_oracle_known_answers.py).
+ *
+ * What is restated (reference paths relative to /root/reference):
+ *   seeded solve        LAP/_lapjv_cpp/lapjv_seeded.cpp:19-173
+ *   cold solve          LAP/_lapjv_cpp/lapjv.cpp:323-346
+ *   column reduction    LAP/_lapjv_cpp/lapjv.cpp:8-72
+ *   row reduction (ARR) LAP/_lapjv_cpp/lapjv.cpp:76-149
+ *   shortest paths      LAP/_lapjv_cpp/lapjv.cpp:153-319
+ *
+ * The arithmetic is fp64 add/sub/compare only; association order is the
+ * reference's and is spelled out at every expression that matters.  Build with
+ * -ffp-contract=off (no FMA contraction) -- see oracle/Makefile.
+ *
+ * Besides results, the oracle counts the element visits of the serial phase;
+ * those counters define the algorithmic bytes used by bench.py's roofline
+ * (SURVEY.md section 8(d)): bytes = 8 * elems.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "jv_oracle.h"
+
+#define JVO_LARGE 1000000.0 /* LAP/_lapjv_cpp/lapjv.h:4 */
+
+static void stats_zero(jvo_stats *st)
+{
+    if (st) memset(st, 0, sizeof(*st));
+}
+
+/* ------------------------------------------------------------------------- */
+/* Shortest augmenting paths (reference: lapjv.cpp:153-319)                   */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    int n;
+    const double *C; /* row-major n*n */
+    int *x, *y;      /* row->col, col->row, -1 = free */
+    double *v;       /* column duals */
+    int *pred;       /* per column: predecessor row on the current tree */
+    int *order;      /* permutation of columns: [0,ready) READY, [lo,hi) SCAN, [hi,n) TODO */
+    double *dist;    /* per column tentative distance */
+    jvo_stats *st;
+} sp_state;
+
+/* lapjv.cpp:153-171.  Moves every TODO column whose dist equals the minimum
+ * to the front of order[lo..]; returns the new hi.  The swap sequence is part
+ * of the observable behaviour (it fixes later tie-breaks). */
+static int sp_collect_minima(sp_state *s, int lo)
+{
+    int hi = lo + 1;
+    double best = s->dist[s->order[lo]];
+    for (int k = hi; k < s->n; ++k) {
+        const int j = s->order[k];
+        const double dj = s->dist[j];
+        if (dj <= best) {
+            if (dj < best) {
+                hi = lo;
+                best = dj;
+            }
+            s->order[k] = s->order[hi];
+            s->order[hi] = j;
+            ++hi;
+        }
+    }
+    if (s->st) s->st->finds++;
+    return hi;
+}
+
+/* lapjv.cpp:178-213.  Returns a free column reached at distance `level`, or -1
+ * after the SCAN list has been exhausted (then *plo == *phi). On the early
+ * return *plo / *phi are NOT written back (lapjv.cpp:200-201 vs :210-211). */
+static int sp_relax_scan_list(sp_state *s, int *plo, int *phi)
+{
+    int lo = *plo, hi = *phi;
+    const int n = s->n;
+    while (lo != hi) {
+        int j = s->order[lo++];
+        const int i = s->y[j];
+        const double level = s->dist[j];
+        const double *row = s->C + (size_t)i * n;
+        /* (cost - v) - level : lapjv.cpp:189 */
+        const double h = (row[j] - s->v[j]) - level;
+        if (s->st) {
+            s->st->scan_steps++;
+            s->st->scan_elems += (long long)(n - hi);
+        }
+        for (int k = hi; k < n; ++k) {
+            j = s->order[k];
+            /* (cost - v) - h : lapjv.cpp:195 */
+            const double cand = (row[j] - s->v[j]) - h;
+            if (cand < s->dist[j]) {
+                s->dist[j] = cand;
+                s->pred[j] = i;
+                if (cand == level) {
+                    if (s->y[j] < 0) return j;
+                    s->order[k] = s->order[hi];
+                    s->order[hi] = j;
+                    ++hi;
+                }
+            }
+        }
+    }
+    *plo = lo;
+    *phi = hi;
+    return -1;
+}
+
+/* lapjv.cpp:221-282 */
+static int sp_find_path(sp_state *s, int start_row)
+{
+    const int n = s->n;
+    int lo = 0, hi = 0, ready = 0, target = -1;
+    const double *row = s->C + (size_t)start_row * n;
+    for (int j = 0; j < n; ++j) {
+        s->order[j] = j;
+        s->pred[j] = start_row;
+        s->dist[j] = row[j] - s->v[j];
+    }
+    if (s->st) {
+        s->st->paths++;
+        s->st->init_elems += n;
+    }
+    while (target == -1) {
+        if (lo == hi) {
+            ready = lo;
+            hi = sp_collect_minima(s, lo);
+            for (int k = lo; k < hi; ++k) {
+                const int j = s->order[k];
+                if (s->y[j] < 0) target = j; /* last one wins: lapjv.cpp:250-255 */
+            }
+        }
+        if (target == -1) target = sp_relax_scan_list(s, &lo, &hi);
+    }
+    {
+        /* lo still indexes the first column of the current level here
+         * (see the early-return note above): lapjv.cpp:270-276 */
+        const double level = s->dist[s->order[lo]];
+        for (int k = 0; k < ready; ++k) {
+            const int j = s->order[k];
+            s->v[j] += s->dist[j] - level;
+        }
+    }
+    return target;
+}
+
+/* lapjv.cpp:286-319 */
+static int sp_augment_all(int n, const double *C, int n_free, const int *free_rows,
+                          int *x, int *y, double *v, jvo_stats *st)
+{
+    sp_state s;
+    s.n = n;
+    s.C = C;
+    s.x = x;
+    s.y = y;
+    s.v = v;
+    s.st = st;
+    s.pred = (int *)malloc(sizeof(int) * (size_t)n);
+    s.order = (int *)malloc(sizeof(int) * (size_t)n);
+    s.dist = (double *)malloc(sizeof(double) * (size_t)n);
+    if (!s.pred || !s.order || !s.dist) {
+        free(s.pred);
+        free(s.order);
+        free(s.dist);
+        return -1;
+    }
+    for (int f = 0; f < n_free; ++f) {
+        const int start = free_rows[f];
+        int j = sp_find_path(&s, start);
+        int i = -1;
+        while (i != start) {
+            i = s.pred[j];
+            y[j] = i;
+            const int prev = x[i];
+            x[i] = j;
+            j = prev;
+        }
+    }
+    free(s.pred);
+    free(s.order);
+    free(s.dist);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Cold JV: column reduction + reduction transfer (lapjv.cpp:8-72)            */
+/* ------------------------------------------------------------------------- */
+static int cold_column_reduction(int n, const double *C, int *free_rows, int *x, int *y,
+                                 double *v, jvo_stats *st)
+{
+    for (int i = 0; i < n; ++i) {
+        x[i] = -1;
+        v[i] = JVO_LARGE;
+        y[i] = 0;
+    }
+    /* strict '<': smallest row index wins a tie; entries >= LARGE never win */
+    for (int i = 0; i < n; ++i) {
+        const double *row = C + (size_t)i * n;
+        for (int j = 0; j < n; ++j) {
+            if (row[j] < v[j]) {
+                v[j] = row[j];
+                y[j] = i;
+            }
+        }
+    }
+    if (st) st->colred_elems += (long long)n * n;
+
+    char *unique = (char *)malloc((size_t)n);
+    if (!unique) return -1;
+    memset(unique, 1, (size_t)n);
+    /* columns visited from n-1 down to 0: lapjv.cpp:36-47 */
+    for (int j = n - 1; j >= 0; --j) {
+        const int i = y[j];
+        if (x[i] < 0) {
+            x[i] = j;
+        } else {
+            unique[i] = 0;
+            y[j] = -1;
+        }
+    }
+    int n_free = 0;
+    for (int i = 0; i < n; ++i) {
+        if (x[i] < 0) {
+            free_rows[n_free++] = i;
+        } else if (unique[i]) {
+            const int j = x[i];
+            const double *row = C + (size_t)i * n;
+            double m = JVO_LARGE;
+            for (int j2 = 0; j2 < n; ++j2) {
+                if (j2 == j) continue;
+                const double c = row[j2] - v[j2];
+                if (c < m) m = c;
+            }
+            v[j] -= m;
+            if (st) st->transfer_rows++;
+        }
+    }
+    free(unique);
+    return n_free;
+}
+
+/* Augmenting row reduction (lapjv.cpp:76-149). All counters are unsigned 32
+ * bit as in the reference (uint_t), including the product current*n. */
+static int cold_row_reduction(int n_, const double *C, unsigned n_free_rows, int *free_rows,
+                              int *x, int *y, double *v, jvo_stats *st)
+{
+    const unsigned n = (unsigned)n_;
+    unsigned current = 0, rr_cnt = 0;
+    int new_free = 0;
+    while (current < n_free_rows) {
+        rr_cnt++;
+        const int free_i = free_rows[current++];
+        const double *row = C + (size_t)free_i * n;
+        int j1 = 0, j2 = -1;
+        double v1 = row[0] - v[0];
+        double v2 = JVO_LARGE;
+        for (unsigned j = 1; j < n; ++j) {
+            const double c = row[j] - v[j];
+            if (c < v2) {
+                if (c >= v1) {
+                    v2 = c;
+                    j2 = (int)j;
+                } else {
+                    v2 = v1;
+                    v1 = c;
+                    j2 = j1;
+                    j1 = (int)j;
+                }
+            }
+        }
+        if (st) st->arr_iters++;
+        int i0 = y[j1];
+        const double v1_new = v[j1] - (v2 - v1); /* lapjv.cpp:117 */
+        const int lowers = v1_new < v[j1];
+        if (rr_cnt < current * n) {
+            if (lowers) {
+                v[j1] = v1_new;
+            } else if (i0 >= 0 && j2 >= 0) {
+                j1 = j2;
+                i0 = y[j2];
+            }
+            if (i0 >= 0) {
+                if (lowers)
+                    free_rows[--current] = i0;
+                else
+                    free_rows[new_free++] = i0;
+            }
+        } else if (i0 >= 0) {
+            free_rows[new_free++] = i0;
+        }
+        x[free_i] = j1;
+        y[j1] = free_i;
+    }
+    return new_free;
+}
+
+/* lapjv.cpp:323-346 */
+static int cold_solve(int n, const double *C, int *x, int *y, jvo_stats *st)
+{
+    int *free_rows = (int *)malloc(sizeof(int) * (size_t)n);
+    double *v = (double *)malloc(sizeof(double) * (size_t)n);
+    if (!free_rows || !v) {
+        free(free_rows);
+        free(v);
+        return -1;
+    }
+    int ret = cold_column_reduction(n, C, free_rows, x, y, v, st);
+    for (int sweep = 0; ret > 0 && sweep < 2; ++sweep)
+        ret = cold_row_reduction(n, C, (unsigned)ret, free_rows, x, y, v, st);
+    if (ret > 0) {
+        if (st) st->free_rows = ret;
+        ret = sp_augment_all(n, C, ret, free_rows, x, y, v, st);
+    }
+    free(v);
+    free(free_rows);
+    return ret;
+}
+
+int jvo_lapjv_dense(const double *C, int n, int *x, int *y, jvo_stats *st)
+{
+    stats_zero(st);
+    if (n <= 0) return -2;
+    if (st) st->branch = JVO_BRANCH_COLD;
+    return cold_solve(n, C, x, y, st);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Seeded solve (lapjv_seeded.cpp:19-173), phases P0..P10 of SURVEY App. A     */
+/* ------------------------------------------------------------------------- */
+int jvo_lapjv_seeded_ex(const double *C, int n_rows, int n_cols, long long *x_out,
+                        long long *y_out, const double *u_seed, const double *v_seed, double eps,
+                        jvo_stats *st, double *u_final, double *v_final)
+{
+    stats_zero(st);
+    if (n_rows <= 0 || n_cols <= 0) return -2; /* :25 */
+    if (n_rows != n_cols) return -4;           /* :27 */
+    const int n = n_rows;
+    int ret = 0;
+
+    int *x = (int *)malloc(sizeof(int) * (size_t)n);
+    int *y = (int *)malloc(sizeof(int) * (size_t)n);
+    double *u = (double *)malloc(sizeof(double) * (size_t)n);
+    double *v = (double *)malloc(sizeof(double) * (size_t)n);
+    int *free_rows = (int *)malloc(sizeof(int) * (size_t)n);
+    char *col_free = (char *)malloc((size_t)n);
+    if (!x || !y || !u || !v || !free_rows || !col_free) {
+        ret = -1;
+        goto done;
+    }
+    for (int i = 0; i < n; ++i) {
+        x[i] = -1;
+        y[i] = -1;
+    }
+    memcpy(u, u_seed, sizeof(double) * (size_t)n);
+    memcpy(v, v_seed, sizeof(double) * (size_t)n);
+
+    /* P1 projection, Gauss-Seidel in row-major order (:38-48): (u+v)-C */
+    for (int i = 0; i < n; ++i) {
+        const double *row = C + (size_t)i * n;
+        for (int j = 0; j < n; ++j) {
+            const double viol = (u[i] + v[j]) - row[j];
+            if (viol > eps) {
+                const double half = viol / 2.0;
+                u[i] -= half;
+                v[j] -= half;
+                if (st) st->proj_events++;
+            }
+        }
+    }
+    /* P2 verify (:9-17,:51-53): (C-u)-v < -eps */
+    for (int i = 0; i < n; ++i) {
+        const double *row = C + (size_t)i * n;
+        for (int j = 0; j < n; ++j) {
+            if ((row[j] - u[i]) - v[j] < -eps) {
+                ret = -3;
+                goto done;
+            }
+        }
+    }
+    /* P3 row tightening (:66-73) */
+    for (int i = 0; i < n; ++i) {
+        const double *row = C + (size_t)i * n;
+        double m = INFINITY;
+        for (int j = 0; j < n; ++j) {
+            const double r = row[j] - v[j];
+            m = (r < m) ? r : m; /* std::min(m, r) */
+        }
+        u[i] = m;
+    }
+    const double tight_eps = (eps < 1e-9) ? 1e-9 : eps; /* std::max(eps,1e-9) :76 */
+
+    /* P4 greedy matching on tight edges (:79-93) */
+    memset(col_free, 1, (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const double *row = C + (size_t)i * n;
+        for (int j = 0; j < n; ++j) {
+            if (!col_free[j]) continue;
+            const double r = (row[j] - u[i]) - v[j];
+            if (fabs(r) <= tight_eps) {
+                x[i] = j;
+                y[j] = i;
+                col_free[j] = 0;
+                break;
+            }
+        }
+    }
+    /* P5 free rows ascending (:96-102); col_free[] is the P5 column snapshot */
+    int n_free = 0;
+    for (int i = 0; i < n; ++i)
+        if (x[i] < 0) free_rows[n_free++] = i;
+
+    /* P6 quality gate (:105-125) */
+    long long tight = 0;
+    for (int i = 0; i < n; ++i) {
+        const double *row = C + (size_t)i * n;
+        for (int j = 0; j < n; ++j) {
+            const double r = (row[j] - u[i]) - v[j];
+            if (fabs(r) <= tight_eps) tight++;
+        }
+    }
+    if (st) {
+        st->tight_edges = tight;
+        st->free_rows = n_free;
+    }
+    if ((double)(int)tight < 1.2 * n) {
+        if (st) st->branch = JVO_BRANCH_FALLBACK;
+        ret = cold_solve(n, C, x, y, st);
+        if (ret != 0) goto done;
+        goto emit;
+    }
+    /* P7 (:128-132) */
+    if (n_free == 0) {
+        if (st) st->branch = JVO_BRANCH_ALL_MATCHED;
+        goto emit;
+    }
+    if (st) st->branch = JVO_BRANCH_SSP;
+
+    /* P8 micro-ARR on the free rows (:136-159) */
+    for (int f = 0; f < n_free; ++f) {
+        const int i = free_rows[f];
+        const double *row = C + (size_t)i * n;
+        double m1 = INFINITY, m2 = INFINITY;
+        int j1 = -1;
+        for (int j = 0; j < n; ++j) {
+            const double r = (row[j] - u[i]) - v[j];
+            if (r < m1) {
+                m2 = m1;
+                m1 = r;
+                j1 = j;
+            } else if (r < m2) {
+                m2 = r;
+            }
+        }
+        if (j1 >= 0 && m2 - m1 > tight_eps && col_free[j1]) {
+            v[j1] += m2 - m1;
+            if (st) st->arr_fired++;
+        }
+    }
+    /* P9 shortest augmenting paths for the free rows (:162-167) */
+    ret = sp_augment_all(n, C, n_free, free_rows, x, y, v, st);
+    if (ret != 0) goto done;
+
+emit:
+    for (int i = 0; i < n; ++i) {
+        x_out[i] = x[i];
+        y_out[i] = y[i];
+    }
+    if (u_final) memcpy(u_final, u, sizeof(double) * (size_t)n);
+    if (v_final) memcpy(v_final, v, sizeof(double) * (size_t)n);
+done:
+    free(x);
+    free(y);
+    free(u);
+    free(v);
+    free(free_rows);
+    free(col_free);
+    return ret;
+}
+
+int jvo_lapjv_seeded(const double *C, int n_rows, int n_cols, long long *x, long long *y,
+                     const double *u_seed, const double *v_seed, double eps)
+{
+    return jvo_lapjv_seeded_ex(C, n_rows, n_cols, x, y, u_seed, v_seed, eps, NULL, NULL, NULL);
+}

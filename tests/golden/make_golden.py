@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ FROM THE REFERENCE.
+
+Runs only where /root/reference exists (the build container).  It
+  * loads the reference's Python modules by file path (gnn/features.py,
+    gnn/one_gnn.py, solvers/advanced_dual.py) -- imported, never copied;
+  * calls the reference's C++ solver through oracle/_ref/liblap_ref.so, which
+    oracle/Makefile compiles from the reference's own sources where they lie;
+and stores inputs + expected outputs as small .npz fixtures.  The fixtures are
+data only; the GPU box and the test-suite never need the reference.
+
+Usage:  python tests/golden/make_golden.py          (from the repo root)
+"""
+from __future__ import annotations
+
+import importlib.util
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[2]
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+from oracle import ref as ref_lib  # noqa: E402
+
+
+def load_by_path(name: str, path: Path):
+    spec = importlib.util.spec_from_file_location(name, str(path))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+ref_features = load_by_path("_ref_features", REF / "gnn" / "features.py")
+ref_one_gnn = load_by_path("_ref_one_gnn", REF / "gnn" / "one_gnn.py")
+ref_dual = load_by_path("_ref_advanced_dual", REF / "solvers" / "advanced_dual.py")
+gen = load_by_path("_our_generators",
+                   ROOT / "gnn-accelerated-lap-warm-start-pipeline_amd" / "solvers" / "generators.py")
+
+
+# --------------------------------------------------------------------------- inputs
+def family(name: str, n: int, seed: int) -> np.ndarray:
+    rs = np.random.RandomState(seed)
+    if name == "int9":      # heavy integer ties
+        return rs.randint(1, 10, size=(n, n)).astype(np.float64)
+    if name == "int100":
+        return rs.randint(1, 101, size=(n, n)).astype(np.float64)
+    if name == "twozero":   # tight = 2n, greedy matches everything
+        C = np.ones((n, n))
+        i = np.arange(n)
+        C[i, i] = 0.0
+        C[i, (i + 1) % n] = 0.0
+        return C
+    if name == "uniform1e8":
+        return rs.uniform(0, 1e8, size=(n, n))
+    if name == "identity":
+        return gen.generate_identity_like_costs(n)
+    if name == "worst":
+        return gen.generate_worst_case_costs(n)
+    return gen.generate_family(name, n, seed)
+
+
+def seeds(kind: str, C: np.ndarray, seed: int):
+    n = C.shape[0]
+    rs = np.random.RandomState(seed + 7919)
+    scale = float(np.median(C[C < 1e5])) if (C < 1e5).any() else 1.0
+    if kind == "zeros":
+        return np.zeros(n), np.zeros(n)
+    if kind == "rowmin":            # untrained-GNN quality, fp64 min-trick (P1 no-op)
+        u = C.min(1)
+        return u, (C - u[:, None]).min(0)
+    if kind == "rowmin32":          # v from an f32 min-trick: P1 fires
+        u = C.min(1).astype(np.float32)
+        v = np.min(C.astype(np.float32) - u[:, None], axis=0)
+        return u.astype(np.float64), v.astype(np.float64)
+    if kind == "noisy":             # noisy (u, v): P1 fires a lot, -3 on 1e6 fills
+        u = C.min(1) + rs.normal(0, 0.05 * scale, n)
+        v = (C - u[:, None]).min(0) + rs.normal(0, 0.05 * scale, n)
+        return u, v
+    if kind == "randu":             # arbitrary u, exact min-trick v
+        u = rs.normal(0, 0.3 * scale, n)
+        return u, (C - u[:, None]).min(0)
+    if kind == "arr":               # ARR can fire at 1e8 scale
+        u = C.min(1) + rs.normal(0, 0.02 * 1e8, n)
+        return u, (C - u[:, None]).min(0)
+    if kind == "huge":              # noise at the 1e5 scale of the sparse fill: ret -3 cases
+        u = C.min(1) + rs.normal(0, 1e5, n)
+        v = (C - u[:, None]).min(0) + rs.normal(0, 1e5, n)
+        return u, v
+    if kind == "optimal":           # near-oracle duals from the reference's own cold solve
+        _, x, _ = ref_lib.dense_raw(C)
+        u, v = ref_dual.project_feasible(C, C.min(1), np.zeros(n))
+        return u, v
+    raise KeyError(kind)
+
+
+# --------------------------------------------------------------------------- seeded solver
+def make_seeded():
+    cases = []
+
+    def add(label, C, u, v, eps=1e-12):
+        ret, x, y = ref_lib.seeded_raw(C, u, v, eps)
+        cases.append(dict(label=label, C=C, u=u, v=v, eps=eps, ret=ret, x=x, y=y))
+
+    # the reference's two print-style demos (LAP/test_seeded.py:9-25, LAP/demo_seeded.py:18-37)
+    add("demo3x3/zeros", np.array([[4., 1., 3.], [2., 0., 5.], [3., 2., 2.]]), np.zeros(3), np.zeros(3))
+    C4 = np.array([[4., 2., 8., 6.], [6., 4., 1., 2.], [8., 6., 4., 3.], [2., 8., 5., 7.]])
+    add("demo4x4/feasible", C4, np.zeros(4), np.array([2., 2., 1., 2.]))
+    add("demo4x4/infeasible-seed", C4, np.full(4, 10.0), np.zeros(4))
+
+    plan = [
+        ("uniform", [1, 2, 3, 5, 8, 16, 33, 64, 128]),
+        ("int9", [3, 8, 16, 40, 64]),
+        ("int100", [8, 32, 64]),
+        ("tie", [8, 32, 64, 128]),
+        ("sparse", [8, 32, 64, 128]),
+        ("metric", [8, 32, 64]),
+        ("clustered", [16, 64, 128]),
+        ("twozero", [4, 16, 64]),
+        ("identity", [8, 32]),
+        ("worst", [8, 32]),
+        ("low_rank", [16, 64]),
+        ("noisy_linear", [16, 64]),
+    ]
+    seed = 1000
+    for fam, sizes in plan:
+        for n in sizes:
+            for kind in ("zeros", "rowmin", "rowmin32", "noisy", "randu"):
+                seed += 1
+                C = family(fam, n, seed)
+                u, v = seeds(kind, C, seed)
+                add(f"{fam}/n{n}/{kind}", C, u, v)
+    # ARR-firing hunt at 1e8 scale (keep only cases where the duals differ from a
+    # non-ARR run is not observable from outside; keep a handful regardless)
+    for n in (8, 32, 128):
+        for rep in range(6):
+            seed += 1
+            C = family("uniform1e8", n, seed)
+            u, v = seeds("arr", C, seed)
+            add(f"uniform1e8/n{n}/arr{rep}", C, u, v)
+    # ret == -3: sparse fill (1e6) with noise at that scale
+    for n in (8, 32, 64):
+        for rep in range(4):
+            seed += 1
+            C = family("sparse", n, seed)
+            u, v = seeds("huge", C, seed)
+            add(f"sparse/n{n}/huge{rep}", C, u, v)
+    # custom eps values
+    for eps in (1e-9, 1e-6, 0.0):
+        seed += 1
+        C = family("uniform", 48, seed)
+        u, v = seeds("rowmin32", C, seed)
+        add(f"uniform/n48/rowmin32/eps{eps:g}", C, u, v, eps)
+
+    rets = {}
+    for c in cases:
+        rets[c["ret"]] = rets.get(c["ret"], 0) + 1
+    print(f"seeded: {len(cases)} cases, ret histogram {rets}")
+
+    off = np.cumsum([0] + [c["C"].shape[0] for c in cases])
+    off2 = np.cumsum([0] + [c["C"].size for c in cases])
+    np.savez_compressed(
+        OUT / "seeded_cases.npz",
+        labels=np.array([c["label"] for c in cases]),
+        n=np.array([c["C"].shape[0] for c in cases], dtype=np.int64),
+        off_vec=off.astype(np.int64), off_mat=off2.astype(np.int64),
+        C=np.concatenate([c["C"].ravel() for c in cases]),
+        u=np.concatenate([c["u"] for c in cases]),
+        v=np.concatenate([c["v"] for c in cases]),
+        eps=np.array([c["eps"] for c in cases]),
+        ret=np.array([c["ret"] for c in cases], dtype=np.int64),
+        x=np.concatenate([c["x"] for c in cases]),
+        y=np.concatenate([c["y"] for c in cases]),
+    )
+
+
+# --------------------------------------------------------------------------- cold solver
+def make_cold():
+    cases = []
+    seed = 5000
+    for fam, sizes in [("uniform", [1, 2, 3, 8, 33, 64, 128]), ("int9", [3, 8, 32, 64]),
+                       ("int100", [16, 64, 100]), ("tie", [16, 64]), ("sparse", [16, 64]),
+                       ("metric", [16, 64]), ("clustered", [32, 128]), ("worst", [8, 32]),
+                       ("identity", [8]), ("twozero", [8])]:
+        for n in sizes:
+            for rep in range(2):
+                seed += 1
+                C = family(fam, n, seed)
+                ret, x, y = ref_lib.dense_raw(C)
+                cases.append(dict(label=f"{fam}/n{n}/{rep}", C=C, ret=ret, x=x, y=y))
+    print(f"cold: {len(cases)} cases")
+    off = np.cumsum([0] + [c["C"].shape[0] for c in cases])
+    off2 = np.cumsum([0] + [c["C"].size for c in cases])
+    np.savez_compressed(
+        OUT / "cold_cases.npz",
+        labels=np.array([c["label"] for c in cases]),
+        n=np.array([c["C"].shape[0] for c in cases], dtype=np.int64),
+        off_vec=off.astype(np.int64), off_mat=off2.astype(np.int64),
+        C=np.concatenate([c["C"].ravel() for c in cases]),
+        ret=np.array([c["ret"] for c in cases], dtype=np.int64),
+        x=np.concatenate([c["x"] for c in cases]).astype(np.int32),
+        y=np.concatenate([c["y"] for c in cases]).astype(np.int32),
+    )
+
+
+# --------------------------------------------------------------------------- features + duals
+def make_features():
+    out = {}
+    labels = []
+    seed = 9000
+    for fam, sizes in [("uniform", [1, 2, 3, 8, 64, 256]), ("sparse", [8, 64, 200]),
+                       ("tie", [16, 64]), ("metric", [9, 64]), ("clustered", [64]),
+                       ("int9", [8, 33])]:
+        for n in sizes:
+            seed += 1
+            C = family(fam, n, seed)
+            key = f"{fam}_n{n}"
+            labels.append(key)
+            out[f"C__{key}"] = C
+            out[f"feat__{key}"] = ref_features.compute_row_features(C)
+            # dual utilities on the same matrix (solvers/advanced_dual.py)
+            rs = np.random.RandomState(seed)
+            u0 = C.min(1) + rs.normal(0, 0.05, n)
+            v0 = rs.normal(0, 0.05, n)
+            pu, pv = ref_dual.project_feasible(C, u0, v0)
+            out[f"u0__{key}"] = u0
+            out[f"v0__{key}"] = v0
+            out[f"proj_u__{key}"] = pu
+            out[f"proj_v__{key}"] = pv
+            if n <= 64:
+                out[f"red_shift__{key}"] = ref_dual.reduce_costs(C, u0, v0, shift_nonneg=True)
+                out[f"red_noshift__{key}"] = ref_dual.reduce_costs(C, pu, pv, shift_nonneg=False)
+    out["labels"] = np.array(labels)
+    out["empty_shape"] = np.array(ref_features.compute_row_features(np.zeros((0, 0))).shape)
+    out["row_feature_dim"] = np.array(ref_features.ROW_FEATURE_DIM)
+    np.savez_compressed(OUT / "features_cases.npz", **out)
+    print(f"features: {len(labels)} matrices")
+
+
+# --------------------------------------------------------------------------- OneGNN
+def make_onegnn():
+    out = {}
+    configs = [("h64l2", 64, 2, 0), ("h192l4", 192, 4, 0)]
+    for tag, H, L, seed in configs:
+        torch.manual_seed(seed)
+        model = ref_one_gnn.OneGNN(in_dim=21, hidden=H, layers=L, dropout=0.1).eval()
+        # perturb LayerNorm affine + biases so that every parameter matters
+        g = torch.Generator().manual_seed(seed + 1)
+        with torch.no_grad():
+            for name, p in model.named_parameters():
+                if "norm" in name or name.startswith("input_proj.2"):
+                    p.add_(0.1 * torch.randn(p.shape, generator=g))
+        sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        for k, v in sd.items():
+            out[f"sd__{tag}__{k}"] = v.numpy()
+        sizes = [(1, "uniform"), (5, "uniform"), (16, "uniform"), (40, "sparse"), (64, "clustered")] \
+            if H == 64 else [(32, "uniform"), (48, "metric")]
+        for n, fam in sizes:
+            C = family(fam, n, 7000 + n)
+            feat = ref_features.compute_row_features(C)
+            row = torch.from_numpy(feat).float().unsqueeze(0)
+            cost = torch.from_numpy(C).float().unsqueeze(0)
+            mask = torch.ones((1, n), dtype=torch.bool)
+            with torch.inference_mode():
+                u = model(row, cost=cost, mask=mask)["u"].squeeze(0).numpy()
+                u_nocost = model(row, mask=mask)["u"].squeeze(0).numpy()
+            v = np.min(C - u[:, None], axis=0)
+            key = f"{tag}__{fam}_n{n}"
+            out[f"C__{key}"] = C
+            out[f"u__{key}"] = u
+            out[f"u_nocost__{key}"] = u_nocost
+            out[f"v__{key}"] = v.astype(np.float64)
+        # a padded batch: (B=2, n=12) with the last 3 rows of instance 1 masked
+        if H == 64:
+            Cb = np.stack([family("uniform", 12, 7101), family("tie", 12, 7102)])
+            featb = np.stack([ref_features.compute_row_features(c) for c in Cb])
+            maskb = torch.ones((2, 12), dtype=torch.bool)
+            maskb[1, 9:] = False
+            with torch.inference_mode():
+                ub = model(torch.from_numpy(featb).float(), cost=torch.from_numpy(Cb).float(),
+                           mask=maskb)["u"].numpy()
+            out[f"C__{tag}__batch"] = Cb
+            out[f"mask__{tag}__batch"] = maskb.numpy()
+            out[f"u__{tag}__batch"] = ub
+    out["torch_version"] = np.array(torch.__version__)
+    out["numpy_version"] = np.array(np.__version__)
+    np.savez_compressed(OUT / "onegnn_cases.npz", **out)
+    print("onegnn: done")
+
+
+if __name__ == "__main__":
+    assert REF.exists(), "needs /root/reference"
+    assert ref_lib.available(), "oracle/_ref/liblap_ref.so could not be built"
+    make_seeded()
+    make_cold()
+    make_features()
+    make_onegnn()
+    for f in sorted(OUT.glob("*.npz")):
+        print(f.name, f.stat().st_size // 1024, "KiB")
