@@ -1,0 +1,326 @@
+// device_utils.hpp -- wave64 / workgroup primitives shared by the gfx950 kernels.
+//
+// Everything here is written for CDNA4 directly: 64-lane wavefronts, LDS as the
+// cross-wave exchange, no 32-lane assumptions anywhere.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lapwarm {
+
+constexpr int kWave = 64;
+constexpr int kMaxWaves = 16;           // 1024 threads / 64
+constexpr double kLarge = 1000000.0;    // the reference's LARGE sentinel (LAP/_lapjv_cpp/lapjv.h:4)
+
+// per-instance flag bits written by the dense prelude / projection kernels
+constexpr int kFlagHasViolation = 1;    // some (i,j) has (u_i+v_j)-C_ij > eps under the seed duals
+constexpr int kFlagInfeasible = 2;      // some (i,j) has (C_ij-u_i)-v_j < -eps (verify step)
+constexpr int kFlagProjected = 4;       // the projection kernel changed (u,v): prelude must be redone
+
+__device__ __forceinline__ double pos_inf() { return __longlong_as_double(0x7ff0000000000000LL); }
+
+__device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b : a; }
+
+__device__ __forceinline__ bool pair_less(double a, int ia, double b, int ib)
+{
+    return (a < b) || (a == b && ia < ib);
+}
+
+// ---- wave-level reductions (all 64 lanes must be active) --------------------------------
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = dmin(v, __shfl_xor(v, m, kWave));
+    return v;
+}
+
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const int o = __shfl_xor(v, m, kWave);
+        v = (o < v) ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double o = __shfl_xor(v, m, kWave);
+        v = (o > v) ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void wave_min_pair(double &v, int &i)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ov = __shfl_xor(v, m, kWave);
+        const int oi = __shfl_xor(i, m, kWave);
+        if (pair_less(ov, oi, v, i)) {
+            v = ov;
+            i = oi;
+        }
+    }
+}
+
+// Two lexicographically smallest (value, index) pairs; "empty" = (+inf, INT_MAX).
+struct Top2 {
+    double a1;
+    int i1;
+    double a2;
+    int i2;
+};
+
+__device__ __forceinline__ Top2 top2_empty()
+{
+    Top2 t;
+    t.a1 = pos_inf();
+    t.i1 = 0x7fffffff;
+    t.a2 = pos_inf();
+    t.i2 = 0x7fffffff;
+    return t;
+}
+
+__device__ __forceinline__ void top2_push(Top2 &t, double a, int i)
+{
+    if (pair_less(a, i, t.a1, t.i1)) {
+        t.a2 = t.a1;
+        t.i2 = t.i1;
+        t.a1 = a;
+        t.i1 = i;
+    } else if (pair_less(a, i, t.a2, t.i2)) {
+        t.a2 = a;
+        t.i2 = i;
+    }
+}
+
+__device__ __forceinline__ Top2 top2_merge(const Top2 &p, const Top2 &q)
+{
+    Top2 r;
+    if (pair_less(q.a1, q.i1, p.a1, p.i1)) {
+        r.a1 = q.a1;
+        r.i1 = q.i1;
+        if (pair_less(p.a1, p.i1, q.a2, q.i2)) {
+            r.a2 = p.a1;
+            r.i2 = p.i1;
+        } else {
+            r.a2 = q.a2;
+            r.i2 = q.i2;
+        }
+    } else {
+        r.a1 = p.a1;
+        r.i1 = p.i1;
+        if (pair_less(q.a1, q.i1, p.a2, p.i2)) {
+            r.a2 = q.a1;
+            r.i2 = q.i1;
+        } else {
+            r.a2 = p.a2;
+            r.i2 = p.i2;
+        }
+    }
+    return r;
+}
+
+__device__ __forceinline__ Top2 wave_top2(Top2 t)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        Top2 o;
+        o.a1 = __shfl_xor(t.a1, m, kWave);
+        o.i1 = __shfl_xor(t.i1, m, kWave);
+        o.a2 = __shfl_xor(t.a2, m, kWave);
+        o.i2 = __shfl_xor(t.i2, m, kWave);
+        t = top2_merge(t, o);
+    }
+    return t;
+}
+
+// Exclusive prefix-min over the lanes of a wave (lane 0 gets +inf); *total = wave min.
+__device__ __forceinline__ double wave_excl_prefix_min(double x, int lane, double *total)
+{
+    double incl = x;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const double o = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl = dmin(incl, o);
+    }
+    *total = __shfl(incl, kWave - 1, kWave);
+    const double prev = __shfl_up(incl, 1, kWave);
+    return (lane == 0) ? pos_inf() : prev;
+}
+
+// ---- workgroup-level exchange through LDS ------------------------------------------------
+// Two alternating slot sets: call k writes set (k&1), one barrier, then reads it.  A thread
+// can only reach the write of call k+2 after the barrier of call k+1, which every reader of
+// call k has passed, so one barrier per call is enough.
+struct BlockExchange {
+    double d[2][kMaxWaves * 2];
+    double bcast[2];
+    int i[2][kMaxWaves * 2];
+};
+
+struct BlockCtx {
+    int tid, lane, wave, nwaves;
+    int parity;
+    BlockExchange *ex;
+
+    __device__ __forceinline__ void init(BlockExchange *e)
+    {
+        tid = threadIdx.x;
+        lane = tid & (kWave - 1);
+        wave = tid >> 6;
+        nwaves = (blockDim.x + kWave - 1) >> 6;
+        parity = 0;
+        ex = e;
+    }
+
+    __device__ __forceinline__ double min_f64(double v)
+    {
+        v = wave_min(v);
+        const int p = parity;
+        parity ^= 1;
+        if (lane == 0) ex->d[p][wave] = v;
+        __syncthreads();
+        double r = ex->d[p][0];
+        for (int w = 1; w < nwaves; ++w) r = dmin(r, ex->d[p][w]);
+        return r;
+    }
+
+    __device__ __forceinline__ double max_f64(double v)
+    {
+        v = wave_max(v);
+        const int p = parity;
+        parity ^= 1;
+        if (lane == 0) ex->d[p][wave] = v;
+        __syncthreads();
+        double r = ex->d[p][0];
+        for (int w = 1; w < nwaves; ++w) {
+            const double o = ex->d[p][w];
+            r = (o > r) ? o : r;
+        }
+        return r;
+    }
+
+    // deterministic: butterfly inside each wave, then waves in index order
+    __device__ __forceinline__ double sum_f64(double v)
+    {
+        v = wave_sum_f64(v);
+        const int p = parity;
+        parity ^= 1;
+        if (lane == 0) ex->d[p][wave] = v;
+        __syncthreads();
+        double r = ex->d[p][0];
+        for (int w = 1; w < nwaves; ++w) r += ex->d[p][w];
+        return r;
+    }
+
+    __device__ __forceinline__ int min_i32(int v)
+    {
+        v = wave_min_i32(v);
+        const int p = parity;
+        parity ^= 1;
+        if (lane == 0) ex->i[p][wave] = v;
+        __syncthreads();
+        int r = ex->i[p][0];
+        for (int w = 1; w < nwaves; ++w) {
+            const int o = ex->i[p][w];
+            r = (o < r) ? o : r;
+        }
+        return r;
+    }
+
+    __device__ __forceinline__ int sum_i32(int v)
+    {
+        v = wave_sum_i32(v);
+        const int p = parity;
+        parity ^= 1;
+        if (lane == 0) ex->i[p][wave] = v;
+        __syncthreads();
+        int r = 0;
+        for (int w = 0; w < nwaves; ++w) r += ex->i[p][w];
+        return r;
+    }
+
+    __device__ __forceinline__ void min_pair(double &v, int &idx)
+    {
+        wave_min_pair(v, idx);
+        const int p = parity;
+        parity ^= 1;
+        if (lane == 0) {
+            ex->d[p][wave] = v;
+            ex->i[p][wave] = idx;
+        }
+        __syncthreads();
+        double r = ex->d[p][0];
+        int ri = ex->i[p][0];
+        for (int w = 1; w < nwaves; ++w) {
+            const double o = ex->d[p][w];
+            const int oi = ex->i[p][w];
+            if (pair_less(o, oi, r, ri)) {
+                r = o;
+                ri = oi;
+            }
+        }
+        v = r;
+        idx = ri;
+    }
+
+    // top2() that also broadcasts one double owned by thread 0
+    __device__ __forceinline__ Top2 top2_bcast(Top2 t, double *val)
+    {
+        if (tid == 0) ex->bcast[parity] = *val;
+        const int p = parity;
+        t = top2(t);
+        *val = ex->bcast[p];
+        return t;
+    }
+
+    __device__ __forceinline__ Top2 top2(Top2 t)
+    {
+        t = wave_top2(t);
+        const int p = parity;
+        parity ^= 1;
+        if (lane == 0) {
+            ex->d[p][2 * wave] = t.a1;
+            ex->d[p][2 * wave + 1] = t.a2;
+            ex->i[p][2 * wave] = t.i1;
+            ex->i[p][2 * wave + 1] = t.i2;
+        }
+        __syncthreads();
+        Top2 r;
+        r.a1 = ex->d[p][0];
+        r.a2 = ex->d[p][1];
+        r.i1 = ex->i[p][0];
+        r.i2 = ex->i[p][1];
+        for (int w = 1; w < nwaves; ++w) {
+            Top2 o;
+            o.a1 = ex->d[p][2 * w];
+            o.a2 = ex->d[p][2 * w + 1];
+            o.i1 = ex->i[p][2 * w];
+            o.i2 = ex->i[p][2 * w + 1];
+            r = top2_merge(r, o);
+        }
+        return r;
+    }
+};
+
+}  // namespace lapwarm

@@ -1,0 +1,102 @@
+// jv_solver.hpp -- host-visible interface of the per-instance solver kernel (jv_solver.hip)
+// and of the dense sweep kernels (dense_sweeps.hip).  Internal to the shared library; the
+// public C ABI is include/lapwarm_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace lapwarm {
+
+constexpr int kModeSeeded = 0;  // continue from the dense prelude (lapjv_seeded)
+constexpr int kModeCold = 1;    // plain lapjv
+
+constexpr int kBranchSsp = 1;
+constexpr int kBranchAllMatched = 2;
+constexpr int kBranchFallback = 3;
+constexpr int kBranchCold = 4;
+
+constexpr int kStatsPerInstance = 16;
+constexpr size_t kLdsBudgetBytes = 160 * 1024;
+
+struct SolverParams {
+    const double *C;  // [batch][n][n] row-major fp64
+    int n;
+    int batch;
+    int mode;
+    // seeded mode inputs, produced by the prelude kernel
+    const double *u_tight;       // [batch][n]      u after row tightening (P3)
+    const double *v_work;        // [batch][n]      v after the (optional) projection
+    const int *tight_cnt;        // [batch][n]      tight edges per row
+    const uint32_t *tight_bits;  // [batch][n][W]   tight-edge bitmap per row, W = ceil(n/32)
+    const int *inst_flags;       // [batch]
+    double tight_eps;
+    // outputs
+    long long *x_out, *y_out;  // [batch][n] int64 (seeded API) or null
+    int *x32_out, *y32_out;    // [batch][n] int32 (lapjv API) or null
+    double *v_out;             // [batch][n] final column duals or null
+    int *ret;                  // [batch]
+    long long *stats;          // [batch][kStatsPerInstance] or null
+    // per-instance state in global memory, only used when the state does not fit LDS
+    double *g_dist, *g_v;
+    int *g_order, *g_pred, *g_y, *g_x, *g_fr;
+};
+
+size_t solver_lds_bytes(int n, bool lds_state);
+bool solver_fits_lds(int n);
+void solver_geometry(int n, int threads_hint, int *threads, int *ch);
+hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t stream);
+
+// ---- dense sweeps (dense_sweeps.hip) ----------------------------------------------------
+struct PreludeParams {
+    const double *C;
+    int n, batch;
+    const double *u;  // [batch][n] duals the verify step uses (seed, or projected)
+    const double *v;  // [batch][n]
+    double eps, tight_eps;
+    int rerun;        // 0: first pass; 1: only instances whose duals were projected
+    double *u_tight;
+    int *viol_cnt;    // [batch][n] candidates of the projection per row (first pass only)
+    int *tight_cnt;
+    uint32_t *tight_bits;
+    int *inst_flags;
+};
+hipError_t launch_prelude(const PreludeParams &p, hipStream_t stream);
+
+// Gauss-Seidel projection of (u, v) for the instances flagged kFlagHasViolation; in place.
+hipError_t launch_projection(const double *C, int n, int batch, double *u, double *v,
+                             const int *viol_cnt, int *inst_flags, double eps, hipStream_t stream);
+
+// out[b][j] = min_i (C[b][i][j] - (u ? u[b][i] : 0)); `partial` holds batch*chunks*n doubles.
+int colmin_chunks(int n, int batch);
+hipError_t launch_colmin(const double *C, int n, int batch, const double *u, double *out,
+                         double *partial, hipStream_t stream);
+
+// out[b][i] = min_j (C[b][i][j] - (v ? v[b][j] : 0))
+hipError_t launch_rowmin(const double *C, int n, int batch, const double *v, double *out,
+                         hipStream_t stream);
+
+// R[b][i][j] = (C - u_i) - v_j - shift[b] ; gmin[b] = min_ij ((C - u_i) - v_j)
+hipError_t launch_reduced_min(const double *C, int n, int batch, const double *u, const double *v,
+                              double *gmin_partial, double *gmin, hipStream_t stream);
+hipError_t launch_reduce_costs(const double *C, int n, int batch, const double *u, const double *v,
+                               const double *gmin, int shift_nonneg, double *out, hipStream_t stream);
+// one round of project_feasible's u/v caps: u = min(u, rowmin(C - v)) ; v = min(v, colmin(C - u))
+hipError_t launch_cap_rows(const double *C, int n, int batch, double *u, const double *v,
+                           hipStream_t stream);
+hipError_t launch_cap_cols(const double *C, int n, int batch, const double *u, double *v,
+                           double *partial, hipStream_t stream);
+
+// 13 row statistics + 8 positional encodings (float32) and the 16 smallest costs per row.
+struct FeatureParams {
+    const double *C;
+    int n, batch;
+    const double *colmin;  // [batch][n]
+    const float *posenc;   // [n][8] host-computed table
+    float *feat;           // [batch][n][21]
+    float *topk;           // [batch][n][16] ascending, +inf padded, or null
+};
+hipError_t launch_row_features(const FeatureParams &p, hipStream_t stream);
+
+}  // namespace lapwarm

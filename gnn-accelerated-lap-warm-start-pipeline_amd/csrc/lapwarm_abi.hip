@@ -1,0 +1,478 @@
+// lapwarm_abi.hip -- the C ABI of liblapwarm_hip.so (declared in include/lapwarm_hip.h).
+//
+// Host-pointer entry points stage through a grow-only device arena and call the batched
+// device entry points with batch = 1; the batched entry points only enqueue work on the
+// caller's stream (no allocation, no synchronisation).
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <mutex>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/lapwarm_hip.h"
+#include "jv_solver.hpp"
+
+using namespace lapwarm;
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+int fail(hipError_t e, const char *where)
+{
+    snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+    return -1000 - (int)e;
+}
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return fail(_e, #expr);   \
+    } while (0)
+
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Carver {
+    unsigned char *base;
+    size_t off;
+    template <typename T>
+    T *take(size_t count)
+    {
+        T *p = reinterpret_cast<T *>(base + off);
+        off += align_up(sizeof(T) * count);
+        return p;
+    }
+};
+
+struct SeededWs {
+    double *u_work, *v_work, *u_tight;
+    int *viol_cnt, *tight_cnt, *flags;
+    uint32_t *tight_bits;
+    double *g_dist, *g_v;
+    int *g_order, *g_pred, *g_y, *g_x, *g_fr;
+    size_t bytes;
+};
+
+SeededWs carve_seeded(void *ws, int batch, int n)
+{
+    SeededWs s;
+    Carver c{reinterpret_cast<unsigned char *>(ws), 0};
+    const size_t bn = (size_t)batch * n;
+    const size_t W = (size_t)(n + 31) / 32;
+    s.u_work = c.take<double>(bn);
+    s.v_work = c.take<double>(bn);
+    s.u_tight = c.take<double>(bn);
+    s.viol_cnt = c.take<int>(bn);
+    s.tight_cnt = c.take<int>(bn);
+    s.flags = c.take<int>((size_t)batch);
+    s.tight_bits = c.take<uint32_t>(bn * W);
+    if (!solver_fits_lds(n)) {
+        s.g_dist = c.take<double>(bn);
+        s.g_v = c.take<double>(bn);
+        s.g_order = c.take<int>(bn);
+        s.g_pred = c.take<int>(bn);
+        s.g_y = c.take<int>(bn);
+        s.g_x = c.take<int>(bn);
+        s.g_fr = c.take<int>(bn);
+    } else {
+        s.g_dist = s.g_v = nullptr;
+        s.g_order = s.g_pred = s.g_y = s.g_x = s.g_fr = nullptr;
+    }
+    s.bytes = c.off;
+    return s;
+}
+
+// grow-only device arena for the host-pointer entry points
+struct Arena {
+    std::mutex mu;
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&ptr, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+};
+Arena g_arena;
+
+int check_dims(int batch, int n)
+{
+    if (n <= 0 || batch <= 0) return -2;
+    if (n > 16384) return -5;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *lapwarm_last_error(void) { return g_err; }
+
+int lapwarm_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+const char *lapwarm_build_info(void) { return "liblapwarm_hip gfx950 (hand-written HIP, fp64)"; }
+
+size_t lapwarm_seeded_workspace_bytes(int batch, int n)
+{
+    if (check_dims(batch, n)) return 0;
+    return carve_seeded(nullptr, batch, n).bytes;
+}
+
+size_t lapwarm_sweep_workspace_bytes(int batch, int n)
+{
+    if (check_dims(batch, n)) return 0;
+    const size_t bn = (size_t)batch * n;
+    // column-min partials + column minima + row partials
+    return align_up(sizeof(double) * bn * (size_t)colmin_chunks(n, batch)) + 2 * align_up(sizeof(double) * bn);
+}
+
+int lapwarm_seeded_batched(const double *C, int batch, int n, const double *u_seed,
+                           const double *v_seed, double eps, long long *x, long long *y, int *ret,
+                           long long *stats, void *workspace, size_t workspace_bytes,
+                           int threads_hint, void *stream_)
+{
+    if (int rc = check_dims(batch, n)) return rc;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    SeededWs w = carve_seeded(workspace, batch, n);
+    if (workspace_bytes < w.bytes) {
+        snprintf(g_err, sizeof(g_err), "workspace too small: %zu < %zu", workspace_bytes, w.bytes);
+        return -1;
+    }
+    const size_t vec = sizeof(double) * (size_t)batch * n;
+    HIP_TRY(hipMemcpyAsync(w.u_work, u_seed, vec, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(w.v_work, v_seed, vec, hipMemcpyDeviceToDevice, stream));
+    HIP_TRY(hipMemsetAsync(w.flags, 0, sizeof(int) * (size_t)batch, stream));
+
+    PreludeParams pp;
+    pp.C = C;
+    pp.n = n;
+    pp.batch = batch;
+    pp.u = w.u_work;
+    pp.v = w.v_work;
+    pp.eps = eps;
+    pp.tight_eps = (eps < 1e-9) ? 1e-9 : eps;  // std::max(eps, 1e-9), lapjv_seeded.cpp:76
+    pp.rerun = 0;
+    pp.u_tight = w.u_tight;
+    pp.viol_cnt = w.viol_cnt;
+    pp.tight_cnt = w.tight_cnt;
+    pp.tight_bits = w.tight_bits;
+    pp.inst_flags = w.flags;
+    HIP_TRY(launch_prelude(pp, stream));
+    HIP_TRY(launch_projection(C, n, batch, w.u_work, w.v_work, w.viol_cnt, w.flags, eps, stream));
+    pp.rerun = 1;
+    HIP_TRY(launch_prelude(pp, stream));
+
+    SolverParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.C = C;
+    sp.n = n;
+    sp.batch = batch;
+    sp.mode = kModeSeeded;
+    sp.u_tight = w.u_tight;
+    sp.v_work = w.v_work;
+    sp.tight_cnt = w.tight_cnt;
+    sp.tight_bits = w.tight_bits;
+    sp.inst_flags = w.flags;
+    sp.tight_eps = pp.tight_eps;
+    sp.x_out = x;
+    sp.y_out = y;
+    sp.ret = ret;
+    sp.stats = stats;
+    sp.g_dist = w.g_dist;
+    sp.g_v = w.g_v;
+    sp.g_order = w.g_order;
+    sp.g_pred = w.g_pred;
+    sp.g_y = w.g_y;
+    sp.g_x = w.g_x;
+    sp.g_fr = w.g_fr;
+    HIP_TRY(launch_solver(sp, threads_hint, stream));
+    return 0;
+}
+
+int lapwarm_lapjv_batched(const double *C, int batch, int n, int *x, int *y, int *ret,
+                          long long *stats, void *workspace, size_t workspace_bytes,
+                          int threads_hint, void *stream_)
+{
+    if (int rc = check_dims(batch, n)) return rc;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    SeededWs w = carve_seeded(workspace, batch, n);
+    if (workspace_bytes < w.bytes) {
+        snprintf(g_err, sizeof(g_err), "workspace too small: %zu < %zu", workspace_bytes, w.bytes);
+        return -1;
+    }
+    SolverParams sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.C = C;
+    sp.n = n;
+    sp.batch = batch;
+    sp.mode = kModeCold;
+    sp.x32_out = x;
+    sp.y32_out = y;
+    sp.ret = ret;
+    sp.stats = stats;
+    sp.g_dist = w.g_dist;
+    sp.g_v = w.g_v;
+    sp.g_order = w.g_order;
+    sp.g_pred = w.g_pred;
+    sp.g_y = w.g_y;
+    sp.g_x = w.g_x;
+    sp.g_fr = w.g_fr;
+    HIP_TRY(launch_solver(sp, threads_hint, stream));
+    return 0;
+}
+
+int lapwarm_colmin_batched(const double *C, int batch, int n, const double *u, double *out,
+                           void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (int rc = check_dims(batch, n)) return rc;
+    if (workspace_bytes < lapwarm_sweep_workspace_bytes(batch, n)) return -1;
+    HIP_TRY(launch_colmin(C, n, batch, u, out, reinterpret_cast<double *>(workspace),
+                          reinterpret_cast<hipStream_t>(stream_)));
+    return 0;
+}
+
+int lapwarm_row_features_batched(const double *C, int batch, int n, const float *posenc, float *feat,
+                                 float *topk16, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (int rc = check_dims(batch, n)) return rc;
+    if (workspace_bytes < lapwarm_sweep_workspace_bytes(batch, n)) return -1;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const size_t bn = (size_t)batch * n;
+    Carver c{reinterpret_cast<unsigned char *>(workspace), 0};
+    double *partial = c.take<double>(bn * (size_t)colmin_chunks(n, batch));
+    double *colmin = c.take<double>(bn);
+    HIP_TRY(launch_colmin(C, n, batch, nullptr, colmin, partial, stream));
+    FeatureParams fp;
+    fp.C = C;
+    fp.n = n;
+    fp.batch = batch;
+    fp.colmin = colmin;
+    fp.posenc = posenc;
+    fp.feat = feat;
+    fp.topk = topk16;
+    HIP_TRY(launch_row_features(fp, stream));
+    return 0;
+}
+
+int lapwarm_project_round_batched(const double *C, int batch, int n, double *u, double *v,
+                                  double *gmin, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    if (int rc = check_dims(batch, n)) return rc;
+    if (workspace_bytes < lapwarm_sweep_workspace_bytes(batch, n)) return -1;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    const size_t bn = (size_t)batch * n;
+    Carver c{reinterpret_cast<unsigned char *>(workspace), 0};
+    double *partial = c.take<double>(bn * (size_t)colmin_chunks(n, batch));
+    double *rowpart = c.take<double>(bn);
+    HIP_TRY(launch_cap_rows(C, n, batch, u, v, stream));
+    HIP_TRY(launch_cap_cols(C, n, batch, u, v, partial, stream));
+    HIP_TRY(launch_reduced_min(C, n, batch, u, v, rowpart, gmin, stream));
+    return 0;
+}
+
+int lapwarm_reduce_costs_batched(const double *C, int batch, int n, const double *u, const double *v,
+                                 int shift_nonneg, double *out, double *gmin, void *workspace,
+                                 size_t workspace_bytes, void *stream_)
+{
+    if (int rc = check_dims(batch, n)) return rc;
+    if (workspace_bytes < lapwarm_sweep_workspace_bytes(batch, n)) return -1;
+    hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+    double *rowpart = reinterpret_cast<double *>(workspace);
+    HIP_TRY(launch_reduced_min(C, n, batch, u, v, rowpart, gmin, stream));
+    HIP_TRY(launch_reduce_costs(C, n, batch, u, v, gmin, shift_nonneg, out, stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Host-pointer drop-ins
+// ------------------------------------------------------------------------------------------
+int lapjv_seeded(const double *C, int n_rows, int n_cols, long long *x, long long *y,
+                 const double *u_seed, const double *v_seed, double eps)
+{
+    if (n_rows <= 0 || n_cols <= 0) return -2;  // lapjv_seeded.cpp:25
+    if (n_rows != n_cols) return -4;            // lapjv_seeded.cpp:27
+    const int n = n_rows;
+    if (n > 16384) return -5;
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t ws_bytes = lapwarm_seeded_workspace_bytes(1, n);
+    const size_t mat = align_up(sizeof(double) * (size_t)n * n);
+    const size_t vec = align_up(sizeof(double) * (size_t)n);
+    const size_t total = mat + 4 * vec + 256 + ws_bytes;
+    if (g_arena.reserve(total) != hipSuccess) return -1;
+    Carver c{reinterpret_cast<unsigned char *>(g_arena.ptr), 0};
+    double *dC = c.take<double>((size_t)n * n);
+    double *du = c.take<double>(n);
+    double *dv = c.take<double>(n);
+    long long *dx = c.take<long long>(n);
+    long long *dy = c.take<long long>(n);
+    int *dret = c.take<int>(1);
+    void *ws = g_arena.ptr ? reinterpret_cast<unsigned char *>(g_arena.ptr) + c.off : nullptr;
+    HIP_TRY(hipMemcpy(dC, C, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(du, u_seed, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dv, v_seed, sizeof(double) * n, hipMemcpyHostToDevice));
+    int rc = lapwarm_seeded_batched(dC, 1, n, du, dv, eps, dx, dy, dret, nullptr, ws, ws_bytes, 0, nullptr);
+    if (rc) return rc;
+    int ret = 0;
+    HIP_TRY(hipMemcpy(&ret, dret, sizeof(int), hipMemcpyDeviceToHost));
+    if (ret != 0) return ret;
+    HIP_TRY(hipMemcpy(x, dx, sizeof(long long) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(y, dy, sizeof(long long) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int lapwarm_lapjv_dense(const double *C, int n, int *x, int *y)
+{
+    if (n <= 0) return -2;
+    if (n > 16384) return -5;
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t ws_bytes = lapwarm_seeded_workspace_bytes(1, n);
+    const size_t total = align_up(sizeof(double) * (size_t)n * n) + 2 * align_up(sizeof(int) * n) + 256 + ws_bytes;
+    if (g_arena.reserve(total) != hipSuccess) return -1;
+    Carver c{reinterpret_cast<unsigned char *>(g_arena.ptr), 0};
+    double *dC = c.take<double>((size_t)n * n);
+    int *dx = c.take<int>(n);
+    int *dy = c.take<int>(n);
+    int *dret = c.take<int>(1);
+    void *ws = reinterpret_cast<unsigned char *>(g_arena.ptr) + c.off;
+    HIP_TRY(hipMemcpy(dC, C, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
+    int rc = lapwarm_lapjv_batched(dC, 1, n, dx, dy, dret, nullptr, ws, ws_bytes, 0, nullptr);
+    if (rc) return rc;
+    int ret = 0;
+    HIP_TRY(hipMemcpy(&ret, dret, sizeof(int), hipMemcpyDeviceToHost));
+    if (ret != 0) return ret;
+    HIP_TRY(hipMemcpy(x, dx, sizeof(int) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(y, dy, sizeof(int) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+static void host_posenc(int n, float *out)
+{
+    // gnn/features.py:21-31, fp64 then float32
+    static const int freqs[4] = {1, 2, 4, 8};
+    const double scale = (n - 1 > 1) ? (double)(n - 1) : 1.0;
+    for (int i = 0; i < n; ++i) {
+        for (int f = 0; f < 4; ++f) {
+            const double ang = 2.0 * M_PI * (double)i * (double)freqs[f] / scale;
+            out[(size_t)i * 8 + 2 * f] = (float)sin(ang);
+            out[(size_t)i * 8 + 2 * f + 1] = (float)cos(ang);
+        }
+    }
+}
+
+int lapwarm_row_features(const double *C, int n, float *feat, float *topk16)
+{
+    if (n <= 0) return -2;
+    if (n > 16384) return -5;
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t ws_bytes = lapwarm_sweep_workspace_bytes(1, n);
+    const size_t total = align_up(sizeof(double) * (size_t)n * n) + align_up(sizeof(float) * n * 8) +
+                         align_up(sizeof(float) * n * 21) + align_up(sizeof(float) * n * 16) + ws_bytes;
+    if (g_arena.reserve(total) != hipSuccess) return -1;
+    Carver c{reinterpret_cast<unsigned char *>(g_arena.ptr), 0};
+    double *dC = c.take<double>((size_t)n * n);
+    float *dpos = c.take<float>((size_t)n * 8);
+    float *dfeat = c.take<float>((size_t)n * 21);
+    float *dtop = c.take<float>((size_t)n * 16);
+    void *ws = reinterpret_cast<unsigned char *>(g_arena.ptr) + c.off;
+    float *pos = new float[(size_t)n * 8];
+    host_posenc(n, pos);
+    hipError_t e1 = hipMemcpy(dpos, pos, sizeof(float) * n * 8, hipMemcpyHostToDevice);
+    delete[] pos;
+    HIP_TRY(e1);
+    HIP_TRY(hipMemcpy(dC, C, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
+    int rc = lapwarm_row_features_batched(dC, 1, n, dpos, dfeat, dtop, ws, ws_bytes, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(feat, dfeat, sizeof(float) * n * 21, hipMemcpyDeviceToHost));
+    if (topk16) HIP_TRY(hipMemcpy(topk16, dtop, sizeof(float) * n * 16, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int lapwarm_min_trick(const double *C, int n, const double *u, double *v)
+{
+    if (n <= 0) return -2;
+    if (n > 16384) return -5;
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t ws_bytes = lapwarm_sweep_workspace_bytes(1, n);
+    const size_t total = align_up(sizeof(double) * (size_t)n * n) + 2 * align_up(sizeof(double) * n) + ws_bytes;
+    if (g_arena.reserve(total) != hipSuccess) return -1;
+    Carver c{reinterpret_cast<unsigned char *>(g_arena.ptr), 0};
+    double *dC = c.take<double>((size_t)n * n);
+    double *du = c.take<double>(n);
+    double *dv = c.take<double>(n);
+    void *ws = reinterpret_cast<unsigned char *>(g_arena.ptr) + c.off;
+    HIP_TRY(hipMemcpy(dC, C, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
+    if (u) HIP_TRY(hipMemcpy(du, u, sizeof(double) * n, hipMemcpyHostToDevice));
+    int rc = lapwarm_colmin_batched(dC, 1, n, u ? du : nullptr, dv, ws, ws_bytes, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(v, dv, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int lapwarm_project_feasible(const double *C, int n, double *u, double *v, int max_rounds, double tol)
+{
+    if (n <= 0) return -2;
+    if (n > 16384) return -5;
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t ws_bytes = lapwarm_sweep_workspace_bytes(1, n);
+    const size_t total = align_up(sizeof(double) * (size_t)n * n) + 2 * align_up(sizeof(double) * n) + 256 + ws_bytes;
+    if (g_arena.reserve(total) != hipSuccess) return -1;
+    Carver c{reinterpret_cast<unsigned char *>(g_arena.ptr), 0};
+    double *dC = c.take<double>((size_t)n * n);
+    double *du = c.take<double>(n);
+    double *dv = c.take<double>(n);
+    double *dg = c.take<double>(1);
+    void *ws = reinterpret_cast<unsigned char *>(g_arena.ptr) + c.off;
+    HIP_TRY(hipMemcpy(dC, C, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(du, u, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dv, v, sizeof(double) * n, hipMemcpyHostToDevice));
+    const int rounds = (max_rounds < 1) ? 1 : max_rounds;  // max(1, int(max_rounds)), advanced_dual.py:28
+    for (int r = 0; r < rounds; ++r) {
+        int rc = lapwarm_project_round_batched(dC, 1, n, du, dv, dg, ws, ws_bytes, nullptr);
+        if (rc) return rc;
+        double g = 0.0;
+        HIP_TRY(hipMemcpy(&g, dg, sizeof(double), hipMemcpyDeviceToHost));
+        if (g >= -tol) break;
+    }
+    HIP_TRY(hipMemcpy(u, du, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(v, dv, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int lapwarm_reduce_costs(const double *C, int n, const double *u, const double *v, int shift_nonneg,
+                         double *out, double *min_out)
+{
+    if (n <= 0) return -2;
+    if (n > 16384) return -5;
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t ws_bytes = lapwarm_sweep_workspace_bytes(1, n);
+    const size_t total = 2 * align_up(sizeof(double) * (size_t)n * n) + 2 * align_up(sizeof(double) * n) + 256 + ws_bytes;
+    if (g_arena.reserve(total) != hipSuccess) return -1;
+    Carver c{reinterpret_cast<unsigned char *>(g_arena.ptr), 0};
+    double *dC = c.take<double>((size_t)n * n);
+    double *dO = c.take<double>((size_t)n * n);
+    double *du = c.take<double>(n);
+    double *dv = c.take<double>(n);
+    double *dg = c.take<double>(1);
+    void *ws = reinterpret_cast<unsigned char *>(g_arena.ptr) + c.off;
+    HIP_TRY(hipMemcpy(dC, C, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(du, u, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dv, v, sizeof(double) * n, hipMemcpyHostToDevice));
+    int rc = lapwarm_reduce_costs_batched(dC, 1, n, du, dv, shift_nonneg, dO, dg, ws, ws_bytes, nullptr);
+    if (rc) return rc;
+    if (out) HIP_TRY(hipMemcpy(out, dO, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost));
+    if (min_out) HIP_TRY(hipMemcpy(min_out, dg, sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+}  // extern "C"
