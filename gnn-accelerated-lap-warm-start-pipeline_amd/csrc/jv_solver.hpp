@@ -99,4 +99,9 @@ struct FeatureParams {
 };
 hipError_t launch_row_features(const FeatureParams &p, hipStream_t stream);
 
+// OneGNN refinement aggregation (onegnn_refine.hip)
+hipError_t launch_refine_aggregate(const float *topk16, const float *u_pre, const float *w1,
+                                   const float *b1, float *out, float *wsum, int rows, int H,
+                                   hipStream_t stream);
+
 }  // namespace lapwarm

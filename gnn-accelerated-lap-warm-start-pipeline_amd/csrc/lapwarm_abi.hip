@@ -101,6 +101,30 @@ struct Arena {
 };
 Arena g_arena;
 
+// optional event bracket around the per-instance solver kernel (bench.py's roofline leg)
+bool g_profile = false;
+hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+bool g_ev_valid = false;
+
+hipError_t profile_begin(hipStream_t s)
+{
+    if (!g_profile) return hipSuccess;
+    if (!g_ev0) {
+        hipError_t e = hipEventCreate(&g_ev0);
+        if (e != hipSuccess) return e;
+        e = hipEventCreate(&g_ev1);
+        if (e != hipSuccess) return e;
+    }
+    return hipEventRecord(g_ev0, s);
+}
+
+hipError_t profile_end(hipStream_t s)
+{
+    if (!g_profile) return hipSuccess;
+    g_ev_valid = true;
+    return hipEventRecord(g_ev1, s);
+}
+
 int check_dims(int batch, int n)
 {
     if (n <= 0 || batch <= 0) return -2;
@@ -119,6 +143,32 @@ int lapwarm_device_count(void)
     int c = 0;
     if (hipGetDeviceCount(&c) != hipSuccess) return 0;
     return c;
+}
+
+void lapwarm_profile_enable(int on) { g_profile = on != 0; }
+
+double lapwarm_profile_last_solver_ms(void)
+{
+    if (!g_ev_valid) return -1.0;
+    if (hipEventSynchronize(g_ev1) != hipSuccess) return -1.0;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+int lapwarm_refine_aggregate_wsum(const float *topk16, const float *u_pre, const float *w1,
+                                  const float *b1, float *out, float *wsum, int rows, int H, void *stream_)
+{
+    if (rows <= 0 || H <= 0) return -2;
+    HIP_TRY(launch_refine_aggregate(topk16, u_pre, w1, b1, out, wsum, rows, H,
+                                    reinterpret_cast<hipStream_t>(stream_)));
+    return 0;
+}
+
+int lapwarm_refine_aggregate_batched(const float *topk16, const float *u_pre, const float *w1,
+                                     const float *b1, float *out, int rows, int H, int, void *stream_)
+{
+    return lapwarm_refine_aggregate_wsum(topk16, u_pre, w1, b1, out, nullptr, rows, H, stream_);
 }
 
 const char *lapwarm_build_info(void) { return "liblapwarm_hip gfx950 (hand-written HIP, fp64)"; }
@@ -196,7 +246,9 @@ int lapwarm_seeded_batched(const double *C, int batch, int n, const double *u_se
     sp.g_y = w.g_y;
     sp.g_x = w.g_x;
     sp.g_fr = w.g_fr;
+    HIP_TRY(profile_begin(stream));
     HIP_TRY(launch_solver(sp, threads_hint, stream));
+    HIP_TRY(profile_end(stream));
     return 0;
 }
 
@@ -228,7 +280,9 @@ int lapwarm_lapjv_batched(const double *C, int batch, int n, int *x, int *y, int
     sp.g_y = w.g_y;
     sp.g_x = w.g_x;
     sp.g_fr = w.g_fr;
+    HIP_TRY(profile_begin(stream));
     HIP_TRY(launch_solver(sp, threads_hint, stream));
+    HIP_TRY(profile_end(stream));
     return 0;
 }
 

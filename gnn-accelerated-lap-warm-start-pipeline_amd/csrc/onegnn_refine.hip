@@ -1,0 +1,84 @@
+// onegnn_refine.hip -- aggregation half of OneGNN's top-k refinement (gnn/one_gnn.py:139-155).
+//
+// For every row: 16 reduced costs -> softmax weights -> sum_k w_k * GELU(w1*val_k + b1) as an
+// H-vector.  The reference materialises a (B, n, 16, H) edge embedding and pushes it through an
+// H x H GEMM; because that second layer is linear, it commutes with the weighted sum, so this
+// kernel emits the (B, n, H) aggregate and the GEMM runs once per row (16x fewer flops, no
+// 16x intermediate in HBM).  float32 throughout, exact-erf GELU as torch's default.
+#include "device_utils.hpp"
+#include "jv_solver.hpp"
+
+namespace lapwarm {
+namespace {
+
+constexpr int kRefineThreads = 256;
+constexpr int kRowsPerBlock = 16;
+constexpr int kK = 16;
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__global__ void __launch_bounds__(kRefineThreads)
+refine_aggregate_kernel(const float *topk, const float *u_pre, const float *w1, const float *b1,
+                        float *out, float *wsum, int rows, int H)
+{
+    __shared__ float s_val[kRowsPerBlock][kK];
+    __shared__ float s_w[kRowsPerBlock][kK];
+    const int row0 = blockIdx.x * kRowsPerBlock;
+    const int tid = threadIdx.x;
+    // phase 1: one 16-lane group per row computes the softmax weights
+    {
+        const int r = tid >> 4, k = tid & 15;
+        const int row = row0 + r;
+        float val = __int_as_float(0x7f800000);
+        if (row < rows) val = topk[(size_t)row * kK + k] - u_pre[row];
+        const bool ok = isfinite(val);
+        float mn = ok ? val : __int_as_float(0x7f800000);
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) mn = fminf(mn, __shfl_xor(mn, m, 16));
+        float e = ok ? expf(-(val - mn)) : 0.0f;
+        float sum = e;
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 16);
+        const float w = (ok && sum > 0.0f) ? e / sum : 0.0f;
+        s_val[r][k] = ok ? val : 0.0f;
+        s_w[r][k] = w;
+        if (k == 0 && wsum && row < rows) {
+            float tot = 0.0f;
+            // recomputed below from LDS for a fixed order
+            (void)tot;
+        }
+    }
+    __syncthreads();
+    if (wsum && tid < kRowsPerBlock && row0 + tid < rows) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kK; ++k) tot += s_w[tid][k];
+        wsum[row0 + tid] = tot;
+    }
+    // phase 2: every thread walks (row, h) pairs of this block
+    const int total = kRowsPerBlock * H;
+    for (int idx = tid; idx < total; idx += kRefineThreads) {
+        const int r = idx / H, h = idx - r * H;
+        const int row = row0 + r;
+        if (row >= rows) break;
+        const float a = w1[h], c = b1[h];
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kK; ++k) acc += s_w[r][k] * gelu_erf(a * s_val[r][k] + c);
+        out[(size_t)row * H + h] = acc;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_refine_aggregate(const float *topk16, const float *u_pre, const float *w1,
+                                   const float *b1, float *out, float *wsum, int rows, int H,
+                                   hipStream_t stream)
+{
+    const int blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
+    hipLaunchKernelGGL(refine_aggregate_kernel, dim3(blocks), dim3(kRefineThreads), 0, stream, topk16,
+                       u_pre, w1, b1, out, wsum, rows, H);
+    return hipGetLastError();
+}
+
+}  // namespace lapwarm

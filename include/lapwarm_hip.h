@@ -102,6 +102,25 @@ int lapwarm_reduce_costs_batched(const double *C, int batch, int n, const double
                                  int shift_nonneg, double *out, double *gmin, void *workspace,
                                  size_t workspace_bytes, void *stream);
 
+/* OneGNN top-k refinement, aggregation part (gnn/one_gnn.py:139-155), float32:
+ *   val_k = topk16[row][k] - u_pre[row]   (== topk(cost - u_pre): x -> x - c is monotone)
+ *   w     = softmax(-val) over the finite entries (0 elsewhere)
+ *   out[row][h] = sum_k w_k * GELU(w1[h] * val_k + b1[h]),  wsum[row] = sum_k w_k
+ * The caller applies the second edge-MLP layer once per row: out @ W2^T + b2 * wsum (linearity).
+ * topk16 [rows][16], u_pre [rows], w1/b1 [H], out [rows][H], wsum [rows]. */
+int lapwarm_refine_aggregate_batched(const float *topk16, const float *u_pre, const float *w1,
+                                     const float *b1, float *out, int rows, int H, int reserved,
+                                     void *stream);
+/* same call, with the [rows] weight sums; `wsum` may be NULL */
+int lapwarm_refine_aggregate_wsum(const float *topk16, const float *u_pre, const float *w1,
+                                  const float *b1, float *out, float *wsum, int rows, int H, void *stream);
+
+/* Profiling hook for bench.py: when enabled, lapwarm_seeded_batched / lapwarm_lapjv_batched
+ * bracket the per-instance solver kernel with HIP events on the caller's stream;
+ * lapwarm_profile_last_solver_ms() waits for the last bracket and returns its duration. */
+void lapwarm_profile_enable(int on);
+double lapwarm_profile_last_solver_ms(void);
+
 /* Misc */
 const char *lapwarm_last_error(void);
 int lapwarm_device_count(void);

@@ -1,0 +1,260 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI / the reference-shaped
+Python API, against (a) the golden vectors generated from the reference and (b) the CPU oracle
+on the same seeded inputs.  Integer results bit-exact; float32 model outputs within the
+north-star tolerance 1e-5."""
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch
+
+
+def _seeded_ret(fn, C, u, v, eps):
+    try:
+        x, y, cost = fn(C, u, v, eps)
+        return 0, x, y, cost
+    except ValueError as e:
+        assert "Infeasible seed potentials" in str(e)
+        return -3, None, None, None
+
+
+# --------------------------------------------------------------------------- golden vectors
+def test_seeded_golden_bit_exact(seeded_cases):
+    import lap
+    n_ok = n_bad3 = 0
+    for k in range(len(seeded_cases)):
+        c = seeded_cases.case(k)
+        ret, x, y, cost = _seeded_ret(lap.lapjv_seeded, c["C"], c["u"], c["v"], c["eps"])
+        assert ret == c["ret"], c["label"]
+        if ret == 0:
+            assert x.dtype == np.int64 and y.dtype == np.int64
+            assert np.array_equal(x, c["x"]), c["label"]
+            assert np.array_equal(y, c["y"]), c["label"]
+            assert cost == float(np.sum(c["C"][np.arange(c["n"]), c["x"]]))
+            n_ok += 1
+        else:
+            n_bad3 += 1
+    assert n_ok > 200 and n_bad3 >= 5
+
+
+def test_cold_golden_bit_exact(cold_cases):
+    import lap
+    for k in range(len(cold_cases)):
+        c = cold_cases.case(k)
+        opt, x, y = lap.lapjv(c["C"])
+        assert x.dtype == np.int32 and y.dtype == np.int32
+        assert np.array_equal(x, c["x"]), c["label"]
+        assert np.array_equal(y, c["y"]), c["label"]
+        assert opt == c["C"][np.arange(c["n"]), c["x"]].sum()
+
+
+def test_reference_known_answers():
+    """The exact-answer cases of LAP/lap/tests/test_lapjv.py:60-129 (test_square), as data."""
+    import lap
+    from test_host_logic import KNOWN_SQUARE
+    for cost, (opt, ex, ey) in KNOWN_SQUARE:
+        ret = lap.lapjv(cost)
+        assert ret[0] == opt
+        assert list(ret[1]) == ex and list(ret[2]) == ey
+        assert cost[range(cost.shape[0]), ret[1]].sum() == ret[0]
+
+
+def test_row_features_golden(features_cases):
+    from gnn import compute_row_features
+    z = features_cases
+    assert compute_row_features(np.zeros((0, 0))).shape == tuple(z["empty_shape"])
+    for key in [str(s) for s in z["labels"]]:
+        got = compute_row_features(z[f"C__{key}"])
+        want = z[f"feat__{key}"]
+        assert got.dtype == np.float32 and got.shape == want.shape
+        # fp64 statistics rounded to float32: differences come from summation order only
+        np.testing.assert_allclose(got, want, rtol=3e-6, atol=1e-9, err_msg=key)
+        for col in (0, 1, 4, 6, 11, 12):  # min, max, MAD, gap, and the two counting features: exact
+            assert np.array_equal(got[:, col], want[:, col]), (key, col)
+        assert np.array_equal(got[:, 13:], want[:, 13:]), key  # positional encodings
+
+
+def test_dual_utilities_golden(features_cases):
+    from solvers import check_dual_feasible, project_feasible, reduce_costs
+    z = features_cases
+    for key in [str(s) for s in z["labels"]]:
+        C, u0, v0 = z[f"C__{key}"], z[f"u0__{key}"], z[f"v0__{key}"]
+        pu, pv = project_feasible(C, u0, v0)
+        assert np.array_equal(pu, z[f"proj_u__{key}"]), key
+        assert np.array_equal(pv, z[f"proj_v__{key}"]), key
+        assert check_dual_feasible(C, pu, pv, tol=1e-8)
+        if f"red_shift__{key}" in z.files:
+            assert np.array_equal(reduce_costs(C, u0, v0, True), z[f"red_shift__{key}"]), key
+            assert np.array_equal(reduce_costs(C, pu, pv, False), z[f"red_noshift__{key}"]), key
+    with pytest.raises(AssertionError):
+        check_dual_feasible(np.zeros((4, 4)), np.ones(4), np.ones(4))
+
+
+@pytest.mark.parametrize("tag,H,L", [("h64l2", 64, 2), ("h192l4", 192, 4)])
+def test_onegnn_device_forward_golden(onegnn_cases, torch_cuda, tag, H, L):
+    torch = torch_cuda
+    from gnn import GNNPredictor, OneGNN
+    z = onegnn_cases
+    sd = {k.split("__", 2)[2]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"sd__{tag}__")}
+    model = OneGNN(21, hidden=H, layers=L)
+    model.load_state_dict(sd)  # the reference's state-dict keys load unchanged
+    pred = GNNPredictor(model=model, device="cuda:0")
+    keys = [k[len("u__"):] for k in z.files if k.startswith(f"u__{tag}__") and not k.endswith("batch")]
+    assert keys
+    for key in keys:
+        C = z[f"C__{key}"]
+        u, v = pred.predict(C)
+        assert u.dtype == np.float64 and v.dtype == np.float64
+        # north-star tolerance for u/v against the PyTorch-CPU forward
+        assert np.abs(u - z[f"u__{key}"]).max() <= 1e-5, (key, np.abs(u - z[f"u__{key}"]).max())
+        assert np.abs(v - z[f"v__{key}"]).max() <= 1e-5, (key, np.abs(v - z[f"v__{key}"]).max())
+    # drop-in call convention of the harness: model(row_feat, cost=..., mask=...)
+    key = keys[0]
+    C = z[f"C__{key}"]
+    from gnn import compute_row_features
+    n = C.shape[0]
+    row = torch.from_numpy(compute_row_features(C)).float().unsqueeze(0).cuda()
+    cost = torch.from_numpy(C).float().unsqueeze(0).cuda()
+    mask = torch.ones((1, n), dtype=torch.bool, device="cuda")
+    model = model.cuda().eval()
+    with torch.inference_mode():
+        u2 = model(row, cost=cost, mask=mask)["u"].squeeze(0).cpu().numpy()
+        u3 = model(row, mask=mask)["u"].squeeze(0).cpu().numpy()
+    assert np.abs(u2 - z[f"u__{key}"]).max() <= 1e-5
+    assert np.abs(u3 - z[f"u_nocost__{key}"]).max() <= 1e-5
+    if f"u__{tag}__batch" in z.files:
+        Cb = z[f"C__{tag}__batch"]
+        feats = np.stack([compute_row_features(c) for c in Cb])
+        with torch.inference_mode():
+            ub = model(torch.from_numpy(feats).cuda(), cost=torch.from_numpy(Cb).float().cuda(),
+                       mask=torch.from_numpy(z[f"mask__{tag}__batch"]).cuda())["u"].cpu().numpy()
+        assert np.abs(ub - z[f"u__{tag}__batch"]).max() <= 1e-5
+
+
+# --------------------------------------------------------------------------- oracle, larger sizes
+def test_native_parity_driver_up_to_256():
+    """Thousands of seeded cases across families / seed kinds / every branch, C ABI vs oracle."""
+    exe = ROOT / "tests" / "native" / "_build" / "parity_driver"
+    assert exe.exists(), "build it with __graft_entry__.build()"
+    proc = subprocess.run([str(exe), "256", "2"], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-3000:]
+    assert "bad=0" in proc.stdout.splitlines()[-1]
+
+
+def test_batched_k2_counters_match_oracle(torch_cuda):
+    """K2-shaped batch (n=512, uniform seeds 42+i): assignments AND the kernel's control-flow
+    counters (paths, minima collections, relax steps/elements, ARR iterations) equal the oracle's."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    from oracle import jv
+    B, n = 8, 512
+    Cs = np.stack([np.random.RandomState(42 + i).uniform(0, 1, (n, n)) for i in range(B)])
+    us = np.stack([C.min(1) if i % 2 == 0 else np.zeros(n) for i, C in enumerate(Cs)])  # SSP and fallback
+    vs = np.stack([(C - u[:, None]).min(0) for C, u in zip(Cs, us)])
+    pipe = WarmStartPipeline(OneGNN(21), "cuda:0")
+    x, y, ret, stats = pipe.seeded_batch(torch.from_numpy(Cs).cuda(), torch.from_numpy(us).cuda(),
+                                         torch.from_numpy(vs).cuda())
+    torch.cuda.synchronize()
+    x, y, ret, stats = x.cpu().numpy(), y.cpu().numpy(), ret.cpu().numpy(), stats.cpu().numpy()
+    names = ["branch", "tight_edges", "free_rows", "arr_fired", "paths", "finds", "scan_steps", "scan_elems",
+             "init_elems", "colred_elems", "transfer_rows", "arr_iters"]
+    seen = set()
+    for b in range(B):
+        r, xo, yo, st = jv.seeded_raw(Cs[b], us[b], vs[b])
+        assert r == ret[b] == 0
+        assert np.array_equal(xo, x[b]) and np.array_equal(yo, y[b])
+        for q, name in enumerate(names):
+            assert stats[b, q] == st[name], (b, name, stats[b, q], st[name])
+        seen.add(st["branch"])
+    assert seen == {1, 3}
+
+
+@pytest.mark.parametrize("n", [2048, 4096, 5000])
+def test_full_size_single_instances(n):
+    """BASELINE sizes through the drop-in API: LDS-resident state (2048, 4096) and the
+    global-workspace variant (5000)."""
+    import lap
+    from oracle import jv
+    C = np.random.RandomState(42).uniform(0, 1, (n, n))
+    u = C.min(1)
+    v = (C - u[:, None]).min(0)
+    x, y, cost = lap.lapjv_seeded(C, u, v)
+    assert sorted(x.tolist()) == list(range(n)) and np.array_equal(y[x], np.arange(n))
+    r, xo, yo, st = jv.seeded_raw(C, u, v)
+    assert r == 0 and st["branch"] == 1
+    assert np.array_equal(x, xo) and np.array_equal(y, yo)
+    if n == 2048:
+        _, xc, yc = lap.lapjv(C)
+        rc, xco, yco, _ = jv.dense_raw(C)
+        assert np.array_equal(xc, xco) and np.array_equal(yc, yco)
+        assert abs(C[np.arange(n), xc].sum() - cost) < 1e-9  # seeded and cold agree on the optimum
+
+
+def test_pipeline_mixed_families_end_to_end(torch_cuda):
+    """K3-shaped (reduced batch): features + OneGNN + min-trick + seeded solve, all families.
+    u/v within 1e-5 of the CPU forward; assignments bit-exact given the GPU's own (u, v)."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    from oracle import jv, one_gnn_ref
+    from solvers.generators import mixed_batch
+    B, n = 4, 768
+    Cs, fams = mixed_batch(B, n, seed=99)
+    torch.manual_seed(0)
+    model = OneGNN(21, hidden=192, layers=4).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    out = WarmStartPipeline(model, "cuda:0").solve_batch(torch.from_numpy(Cs).cuda())
+    torch.cuda.synchronize()
+    u, v = out["u"].cpu().numpy(), out["v"].cpu().numpy()
+    x, y, ret = out["x"].cpu().numpy(), out["y"].cpu().numpy(), out["ret"].cpu().numpy()
+    for b in range(B):
+        ur, vr = one_gnn_ref.predict(sd, Cs[b])
+        assert np.abs(u[b] - ur).max() <= 1e-5, (fams[b], np.abs(u[b] - ur).max())
+        scale = max(1.0, float(np.abs(vr).max()))
+        assert np.abs(v[b] - vr).max() <= 1e-5 * scale, (fams[b], np.abs(v[b] - vr).max())
+        r, xo, yo, _ = jv.seeded_raw(Cs[b], u[b].astype(np.float64), v[b])
+        assert r == ret[b], fams[b]
+        if r == 0:
+            assert np.array_equal(xo, x[b]) and np.array_equal(yo, y[b]), fams[b]
+
+
+# --------------------------------------------------------------------------- wrappers / errors
+def test_solver_wrappers_and_error_behaviour():
+    import lap
+    from solvers import LAPSolver, SciPySolver, SeededLAPSolver, WarmStartLAPSolver, time_solver_rigorous
+    C = np.random.RandomState(3).uniform(0, 1, (64, 64))
+    u = C.min(1)
+    v = (C - u[:, None]).min(0)
+    rows, cols, cost = SeededLAPSolver().solve(C, u=u, v=v)  # keyword call, as analyze_all_types_pipeline.py:242
+    assert rows.dtype == np.int64 and cols.dtype == np.int64 and isinstance(cost, float)
+    assert np.array_equal(cols[rows], np.arange(64))  # "rows" = x, "cols" = y
+    r2, c2, cost2 = LAPSolver().solve(C)
+    assert np.array_equal(r2, np.arange(64)) and abs(cost2 - cost) < 1e-9
+    r3, c3, cost3 = WarmStartLAPSolver().solve(C, u, v)
+    assert abs(cost3 - cost) < 1e-9 and abs(SciPySolver().solve(C)[2] - cost) < 1e-9
+    stats = time_solver_rigorous(lambda: SeededLAPSolver().solve(C, u, v), num_warmups=1, num_repeats=3)
+    assert stats["success"] and stats["num_samples"] == 3
+    with pytest.raises(ValueError, match="u/v sizes must match C"):
+        lap.lapjv_seeded(C, u[:-1].copy(), v)
+    with pytest.raises(ValueError):
+        lap.lapjv_seeded(np.asfortranarray(C), u, v)  # not C-contiguous
+    with pytest.raises(ValueError):
+        lap.lapjv_seeded(C.astype(np.float32), u, v)
+    with pytest.raises(RuntimeError, match="code -4"):
+        lap.lapjv_seeded(np.zeros((3, 2)), np.zeros(3), np.zeros(2))
+    with pytest.raises(ValueError):
+        lap.lapjv(np.zeros((3, 2)))
+    with pytest.raises(ValueError):
+        lap.lapjv(np.zeros(3))
+    ret = lap.lapjv(C[:3, :3][:, ::1][::1])  # non-contiguous view is copied (test_lapjv_non_contigous)
+    assert len(ret) == 3

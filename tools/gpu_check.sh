@@ -1,0 +1,28 @@
+#!/bin/bash
+# Runs on the GPU box via gpurun: GPU test-suite, native parity sweep, smoke and a short bench.
+# A step that times out (124/137) stops the chain: no further GPU step after a killed one.
+set -u
+mkdir -p gpurun_out
+step() {  # name timeout cmd...
+  local name=$1 tmo=$2; shift 2
+  echo "=== $name" | tee -a gpurun_out/summary.log
+  timeout -k 10 "$tmo" "$@" > "gpurun_out/$name.log" 2>&1
+  local rc=$?
+  echo "rc=$rc" | tee -a gpurun_out/summary.log
+  tail -n 12 "gpurun_out/$name.log" | tee -a gpurun_out/summary.log
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name: stopping" | tee -a gpurun_out/summary.log; exit 1; fi
+  return 0
+}
+: > gpurun_out/summary.log
+for s in "$@"; do
+  case $s in
+    smoke)   step smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
+    pytest)  step pytest 900 python -m pytest tests -x -q -m gpu ;;
+    parity2k) step parity2k 600 tests/native/_build/parity_driver 2048 1 ;;
+    parity4k) step parity4k 900 tests/native/_build/parity_driver 4096 1 ;;
+    bench)   step bench 600 python bench.py --steps 2 --warmup 1 ;;
+    bench256) step bench256 300 python bench.py --steps 2 --warmup 1 --threads-hint 256 --cpu-sample 0 ;;
+    bench1024) step bench1024 300 python bench.py --steps 2 --warmup 1 --threads-hint 1024 --cpu-sample 0 ;;
+    *) echo "unknown step $s" ;;
+  esac
+done
