@@ -100,43 +100,35 @@ __device__ __forceinline__ Top2 top2_empty()
     return t;
 }
 
+// Branch-free selects on values only: passing the structs by reference made the compiler keep
+// them in scratch memory (a select between addresses), which cost ~25 us per ARR iteration.
 __device__ __forceinline__ void top2_push(Top2 &t, double a, int i)
 {
-    if (pair_less(a, i, t.a1, t.i1)) {
-        t.a2 = t.a1;
-        t.i2 = t.i1;
-        t.a1 = a;
-        t.i1 = i;
-    } else if (pair_less(a, i, t.a2, t.i2)) {
-        t.a2 = a;
-        t.i2 = i;
-    }
+    const bool first = pair_less(a, i, t.a1, t.i1);
+    const bool second = pair_less(a, i, t.a2, t.i2);
+    const double n2a = first ? t.a1 : (second ? a : t.a2);
+    const int n2i = first ? t.i1 : (second ? i : t.i2);
+    t.a1 = first ? a : t.a1;
+    t.i1 = first ? i : t.i1;
+    t.a2 = n2a;
+    t.i2 = n2i;
 }
 
-__device__ __forceinline__ Top2 top2_merge(const Top2 &p, const Top2 &q)
+__device__ __forceinline__ Top2 top2_merge(Top2 p, Top2 q)
 {
+    const bool qf = pair_less(q.a1, q.i1, p.a1, p.i1);
+    const double fa = qf ? q.a1 : p.a1;
+    const int fi = qf ? q.i1 : p.i1;
+    const double la = qf ? p.a1 : q.a1;  // the losing head
+    const int li = qf ? p.i1 : q.i1;
+    const double sa = qf ? q.a2 : p.a2;  // the winner's own runner-up
+    const int si = qf ? q.i2 : p.i2;
+    const bool ls = pair_less(la, li, sa, si);
     Top2 r;
-    if (pair_less(q.a1, q.i1, p.a1, p.i1)) {
-        r.a1 = q.a1;
-        r.i1 = q.i1;
-        if (pair_less(p.a1, p.i1, q.a2, q.i2)) {
-            r.a2 = p.a1;
-            r.i2 = p.i1;
-        } else {
-            r.a2 = q.a2;
-            r.i2 = q.i2;
-        }
-    } else {
-        r.a1 = p.a1;
-        r.i1 = p.i1;
-        if (pair_less(q.a1, q.i1, p.a2, p.i2)) {
-            r.a2 = q.a1;
-            r.i2 = q.i1;
-        } else {
-            r.a2 = p.a2;
-            r.i2 = p.i2;
-        }
-    }
+    r.a1 = fa;
+    r.i1 = fi;
+    r.a2 = ls ? la : sa;
+    r.i2 = ls ? li : si;
     return r;
 }
 

@@ -21,7 +21,14 @@
 //     wave 0 only.  Positions above the one being examined are never touched by the serial
 //     loops, so event detection on the pre-loop order is exact; random data has ~ln n events.
 //   * the minima collection that follows an event-free relax step reuses the distances that
-//     are still in registers (no second LDS sweep).
+//     are still in registers (no second LDS sweep);
+//   * the relax loop is batched: up to SMAX queued SCAN columns (they all sit at the same level)
+//     are relaxed in ONE pass -- every TODO position loads its entry of all their rows, then
+//     replays the serial sequence in registers.  A column's evolution inside the batch depends
+//     on no other column; only the ORDER of the tie events does, and that is rebuilt by wave 0
+//     step by step from per-step column bitmaps and the inverse permutation pos[].  Writes made
+//     by the pass after an early return are unobservable (dist/order die with the path, pred is
+//     only read along READY/SCAN columns), so the pass never has to be rolled back.
 #include "device_utils.hpp"
 #include "jv_solver.hpp"
 
@@ -31,27 +38,37 @@ namespace {
 
 struct Ctrl {
     double level;
+    long long batch_elems;
     int hi;
     int target;
     int evt_step;
     int first_fire;
     int nfree;
     int err;
-    int pad0, pad1;
+    unsigned ev_mask;
+    int batch_steps;
+};
+
+template <int CH>
+struct BatchDepth {
+    static constexpr int value = (CH >= 16) ? 1 : (CH == 8 ? 2 : (CH == 4 ? 4 : 8));
 };
 
 constexpr int kSentinelIdx = 0x7ffffffe;  // the LARGE sentinel of the ARR scan (index -1 in the reference)
 constexpr int kEmptyIdx = 0x7fffffff;
 
-template <int CH, bool LDS_STATE>
+template <int CH, int LDSL>
 struct Solver {
+    static constexpr bool LDS_STATE = LDSL > 0;
+    static constexpr int SMAX = BatchDepth<CH>::value;
     // problem
     const double *C;
     int n, W;
     // state
     double *dist, *v;
-    int *order, *pred, *y, *x, *fr;
-    uint32_t *evt, *sbits, *used;
+    int *order, *pred, *y, *x, *fr, *pos;
+    uint32_t *evt, *sbits, *used, *evb, *tmpb;
+    int Wpad;
     Ctrl *ctrl;
     BlockCtx bc;
     // uniform counters (identical in every thread)
@@ -99,7 +116,9 @@ struct Solver {
                     const int a = order[hi];
                     if (lane == 0) {
                         order[k] = a;
+                        pos[a] = k;
                         order[hi] = j;
+                        pos[j] = hi;
                     }
                     fence_if_global();
                     ++hi;
@@ -125,45 +144,81 @@ struct Solver {
         }
     }
 
-    // Relax-loop tie events, lapjv.cpp:199-205.
-    __device__ __forceinline__ void replay_scan(int hi)
+    // Tie events of one batch of relax steps (lapjv.cpp:199-205), replayed step by step.
+    // evb[s] holds, per COLUMN, the events the pass found at step s; their order inside a step
+    // is the order of the columns' positions at that step's start, read from pos[].
+    __device__ __forceinline__ void replay_batch(int hi, int S)
     {
         const int lane = bc.lane;
+        const unsigned mask = ctrl->ev_mask;
         int target = -1;
-        for (int wbase = 0; wbase < W; wbase += kWave) {
-            const int idx = wbase + lane;
-            uint32_t ew = 0;
-            if (idx < W) {
-                ew = evt[idx];
-                if (ew) evt[idx] = 0;
+        long long elems = 0;
+        int steps = 0;
+        for (int st = 0; st < S && target < 0; ++st) {
+            elems += (long long)(n - hi);
+            ++steps;
+            if (!((mask >> st) & 1u)) continue;
+            uint32_t *eb = evb + (size_t)st * Wpad;
+            for (int wbase = 0; wbase < W; wbase += kWave) {
+                const int idx = wbase + lane;
+                uint32_t word = 0;
+                if (idx < W) {
+                    word = eb[idx];
+                    if (word) eb[idx] = 0;
+                }
+                while (word) {
+                    const int bit = __builtin_ctz(word);
+                    word &= word - 1;
+                    const int p = pos[(idx << 5) + bit];
+                    atomicOr(&tmpb[p >> 5], 1u << (p & 31));
+                }
             }
-            unsigned long long mask = __ballot(ew != 0);
-            while (mask && target < 0) {
-                const int l = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                uint32_t e = __shfl(ew, l, kWave);
-                while (e && target < 0) {
-                    const int bit = __builtin_ctz(e);
-                    e &= e - 1;
-                    const int k = ((wbase + l) << 5) + bit;
-                    const int j = order[k];
-                    if (y[j] < 0) {
-                        target = j;
-                    } else {
-                        const int a = order[hi];
-                        if (lane == 0) {
-                            order[k] = a;
-                            order[hi] = j;
+            fence_if_global();
+            for (int wbase = 0; wbase < W; wbase += kWave) {
+                const int idx = wbase + lane;
+                uint32_t tw = 0;
+                if (idx < W) {
+                    tw = tmpb[idx];
+                    if (tw) tmpb[idx] = 0;
+                }
+                unsigned long long m = __ballot(tw != 0);
+                while (m && target < 0) {
+                    const int l = __builtin_ctzll(m);
+                    m &= m - 1;
+                    uint32_t e = __shfl(tw, l, kWave);
+                    while (e && target < 0) {
+                        const int bit = __builtin_ctz(e);
+                        e &= e - 1;
+                        const int p = ((wbase + l) << 5) + bit;
+                        const int j = order[p];
+                        if (y[j] < 0) {
+                            target = j;
+                        } else {
+                            const int a = order[hi];
+                            if (lane == 0) {
+                                order[p] = a;
+                                pos[a] = p;
+                                order[hi] = j;
+                                pos[j] = hi;
+                            }
+                            fence_if_global();
+                            ++hi;
                         }
-                        fence_if_global();
-                        ++hi;
                     }
                 }
             }
         }
+        if (target >= 0) {
+            // early return: drop whatever is still queued in the bitmaps
+            for (int w = lane; w < Wpad; w += kWave) tmpb[w] = 0;
+            for (int w = lane; w < SMAX * Wpad; w += kWave) evb[w] = 0;
+        }
         if (lane == 0) {
             ctrl->hi = hi;
             ctrl->target = target;
+            ctrl->ev_mask = 0;
+            ctrl->batch_elems = elems;
+            ctrl->batch_steps = steps;
         }
     }
 
@@ -182,6 +237,7 @@ struct Solver {
                 if (k < n) {
                     const double val = row[k] - v[k];
                     order[k] = k;
+                    pos[k] = k;
                     pred[k] = start;
                     dist[k] = val;
                     dk[r] = val;
@@ -196,103 +252,125 @@ struct Solver {
         double level = 0.0;
         int guard = 0;
         while (target < 0) {
-            if (++guard > n + 2) {
+            if (++guard > 2 * n + 4) {
                 err = 1;
                 break;
             }
-            // ---------------- minima collection over positions [lo, n)
-            ready = lo;
-            double tmin = pos_inf();
-#pragma unroll
-            for (int r = 0; r < CH; ++r) {
-                const int k = b0 + r;
-                if (k >= lo && k < n) tmin = dmin(tmin, dk[r]);
-            }
-            double wtot;
-            double run = wave_excl_prefix_min(tmin, bc.lane, &wtot);
-            {
-                const int p = bc.parity;
-                bc.parity ^= 1;
-                if (bc.lane == 0) bc.ex->d[p][bc.wave] = wtot;
-                __syncthreads();
-                for (int w = 0; w < bc.wave; ++w) run = dmin(run, bc.ex->d[p][w]);
-            }
-            uint32_t eb = 0, sb = 0;
-#pragma unroll
-            for (int r = 0; r < CH; ++r) {
-                const int k = b0 + r;
-                if (k >= lo && k < n) {
-                    if (k > lo && dk[r] <= run) {
-                        eb |= 1u << r;
-                        if (dk[r] < run) sb |= 1u << r;
-                    }
-                    run = dmin(run, dk[r]);
-                }
-            }
-            if (eb) {
-                atomicOr(&evt[wordi], eb << shift);
-                if (sb) atomicOr(&sbits[wordi], sb << shift);
-            }
-            __syncthreads();
-            if (bc.wave == 0) replay_find(lo);
-            __syncthreads();
-            hi = ctrl->hi;
-            target = ctrl->target;
-            level = ctrl->level;
-            finds++;
-            if (target >= 0) break;
-
-            // ---------------- relax every column of the SCAN list (lapjv.cpp:178-213)
-            int inner = 0;
-            while (lo != hi) {
-                if (++inner > n + 2) {
-                    err = 2;
-                    target = 0;
-                    break;
-                }
-                const int jc = order[lo];
-                ++lo;
-                const int i = y[jc];
-                const double lvl = dist[jc];
-                const double *row = C + (size_t)i * n;
-                const double h = (row[jc] - v[jc]) - lvl;
-                scan_steps++;
-                scan_elems += (long long)(n - hi);
-                uint32_t tb = 0;
+            if (lo == hi) {
+                // ---------------- minima collection over positions [lo, n); dk[] is current
+                ready = lo;
+                double tmin = pos_inf();
 #pragma unroll
                 for (int r = 0; r < CH; ++r) {
                     const int k = b0 + r;
-                    if (k >= hi && k < n) {
-                        const int j = order[k];
-                        const double cand = (row[j] - v[j]) - h;
-                        const double dj = dist[j];
-                        if (cand < dj) {
-                            dist[j] = cand;
-                            pred[j] = i;
-                            dk[r] = cand;
-                            if (cand == lvl) tb |= 1u << r;
-                        } else {
-                            dk[r] = dj;
+                    if (k >= lo && k < n) tmin = dmin(tmin, dk[r]);
+                }
+                double wtot;
+                double run = wave_excl_prefix_min(tmin, bc.lane, &wtot);
+                {
+                    const int p = bc.parity;
+                    bc.parity ^= 1;
+                    if (bc.lane == 0) bc.ex->d[p][bc.wave] = wtot;
+                    __syncthreads();
+                    for (int w = 0; w < bc.wave; ++w) run = dmin(run, bc.ex->d[p][w]);
+                }
+                uint32_t eb = 0, sb = 0;
+#pragma unroll
+                for (int r = 0; r < CH; ++r) {
+                    const int k = b0 + r;
+                    if (k >= lo && k < n) {
+                        if (k > lo && dk[r] <= run) {
+                            eb |= 1u << r;
+                            if (dk[r] < run) sb |= 1u << r;
                         }
-                    } else {
-                        dk[r] = pos_inf();
+                        run = dmin(run, dk[r]);
                     }
                 }
-                if (tb) {
-                    atomicOr(&evt[wordi], tb << shift);
-                    ctrl->evt_step = step_id;
+                if (eb) {
+                    atomicOr(&evt[wordi], eb << shift);
+                    if (sb) atomicOr(&sbits[wordi], sb << shift);
                 }
                 __syncthreads();
-                const bool had_events = (ctrl->evt_step == step_id);
-                if (had_events) {
-                    if (bc.wave == 0) replay_scan(hi);
-                    __syncthreads();
-                    hi = ctrl->hi;
-                    target = ctrl->target;
-                }
-                step_id++;
+                if (bc.wave == 0) replay_find(lo);
+                __syncthreads();
+                hi = ctrl->hi;
+                target = ctrl->target;
+                level = ctrl->level;
+                finds++;
                 if (target >= 0) break;
             }
+            // ---------------- relax a batch of queued SCAN columns (lapjv.cpp:178-213)
+            const int S = (hi - lo < SMAX) ? hi - lo : SMAX;
+            const double *rows[SMAX];
+            double hs[SMAX];
+            int is[SMAX];
+#pragma unroll
+            for (int q = 0; q < SMAX; ++q) {
+                rows[q] = C;
+                hs[q] = 0.0;
+                is[q] = 0;
+                if (q < S) {
+                    const int jc = order[lo + q];
+                    const int i = y[jc];
+                    is[q] = i;
+                    rows[q] = C + (size_t)i * n;
+                    hs[q] = (rows[q][jc] - v[jc]) - level;
+                }
+            }
+            unsigned my_mask = 0;
+#pragma unroll
+            for (int r = 0; r < CH; ++r) {
+                const int k = b0 + r;
+                if (k >= hi && k < n) {
+                    const int j = order[k];
+                    double c[SMAX];
+#pragma unroll
+                    for (int q = 0; q < SMAX; ++q) c[q] = (q < S) ? rows[q][j] : 0.0;
+                    const double vj = v[j];
+                    double dj = dist[j];
+                    int pj = -1, ev = -1;
+#pragma unroll
+                    for (int q = 0; q < SMAX; ++q) {
+                        if (q < S && ev < 0) {
+                            const double cand = (c[q] - vj) - hs[q];
+                            if (cand < dj) {
+                                dj = cand;
+                                pj = is[q];
+                                if (cand == level) ev = q;
+                            }
+                        }
+                    }
+                    if (pj >= 0) {
+                        dist[j] = dj;
+                        pred[j] = pj;
+                    }
+                    dk[r] = dj;
+                    if (ev >= 0) {
+                        atomicOr(&evb[(size_t)ev * Wpad + (j >> 5)], 1u << (j & 31));
+                        my_mask |= 1u << ev;
+                    }
+                } else {
+                    dk[r] = pos_inf();
+                }
+            }
+            if (my_mask) {
+                atomicOr(&ctrl->ev_mask, my_mask);
+                ctrl->evt_step = step_id;
+            }
+            __syncthreads();
+            if (ctrl->evt_step == step_id) {
+                if (bc.wave == 0) replay_batch(hi, S);
+                __syncthreads();
+                hi = ctrl->hi;
+                target = ctrl->target;
+                scan_steps += ctrl->batch_steps;
+                scan_elems += ctrl->batch_elems;
+            } else {
+                scan_steps += S;
+                scan_elems += (long long)S * (n - hi);
+            }
+            step_id++;
+            lo += S;
         }
         // dual update for the READY columns (lapjv.cpp:270-276): v[j] += d[j] - level
 #pragma unroll
@@ -621,7 +699,7 @@ struct Solver {
     }
 };
 
-template <int CH, bool LDS_STATE>
+template <int CH, int LDSL>
 __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -630,7 +708,9 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
     const int W = (n + 31) >> 5;
     const int Wpad = (W + 1) & ~1;
 
-    Solver<CH, LDS_STATE> s;
+    Solver<CH, LDSL> s;
+    constexpr int SMAX = BatchDepth<CH>::value;
+    s.Wpad = Wpad;
     unsigned char *cur = smem;
     BlockExchange *ex = reinterpret_cast<BlockExchange *>(cur);
     cur += sizeof(BlockExchange);
@@ -642,7 +722,11 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
     cur += sizeof(uint32_t) * Wpad;
     s.used = reinterpret_cast<uint32_t *>(cur);
     cur += sizeof(uint32_t) * Wpad;
-    if constexpr (LDS_STATE) {
+    s.tmpb = reinterpret_cast<uint32_t *>(cur);
+    cur += sizeof(uint32_t) * Wpad;
+    s.evb = reinterpret_cast<uint32_t *>(cur);
+    cur += sizeof(uint32_t) * Wpad * SMAX;
+    if constexpr (LDSL > 0) {
         s.dist = reinterpret_cast<double *>(cur);
         cur += sizeof(double) * n;
         s.v = reinterpret_cast<double *>(cur);
@@ -653,9 +737,17 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
         cur += sizeof(int) * n;
         s.y = reinterpret_cast<int *>(cur);
         cur += sizeof(int) * n;
-        s.x = reinterpret_cast<int *>(cur);
+        s.pos = reinterpret_cast<int *>(cur);
         cur += sizeof(int) * n;
-        s.fr = reinterpret_cast<int *>(cur);
+        if constexpr (LDSL > 1) {
+            s.x = reinterpret_cast<int *>(cur);
+            cur += sizeof(int) * n;
+            s.fr = reinterpret_cast<int *>(cur);
+        } else {
+            const size_t o = (size_t)b * n;
+            s.x = p.g_x + o;
+            s.fr = p.g_fr + o;
+        }
     } else {
         const size_t o = (size_t)b * n;
         s.dist = p.g_dist + o;
@@ -665,6 +757,7 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
         s.y = p.g_y + o;
         s.x = p.g_x + o;
         s.fr = p.g_fr + o;
+        s.pos = p.g_pos + o;
     }
     s.bc.init(ex);
     s.C = p.C + (size_t)b * n * n;
@@ -676,6 +769,8 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
     s.err = 0;
 
     const int tid = s.bc.tid;
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    unsigned long long t_serial = t_start;
     const int flags = p.inst_flags ? p.inst_flags[b] : 0;
     if (p.mode == kModeSeeded && (flags & kFlagInfeasible)) {
         if (tid == 0) {
@@ -693,12 +788,17 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
         s.ctrl->nfree = 0;
         s.ctrl->hi = 0;
         s.ctrl->target = -1;
+        s.ctrl->ev_mask = 0;
+        s.ctrl->batch_steps = 0;
+        s.ctrl->batch_elems = 0;
     }
     for (int w = tid; w < Wpad; w += blockDim.x) {
         s.evt[w] = 0;
         s.sbits[w] = 0;
         s.used[w] = 0;
+        s.tmpb[w] = 0;
     }
+    for (int w = tid; w < Wpad * SMAX; w += blockDim.x) s.evb[w] = 0;
     int tight_local = 0;
     for (int j = tid; j < n; j += blockDim.x) {
         s.x[j] = -1;
@@ -730,6 +830,7 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
             } else {
                 branch = kBranchSsp;
                 s.micro_arr(nf, p.u_tight + (size_t)b * n, p.tight_eps);
+                t_serial = __builtin_amdgcn_s_memrealtime();
                 if (!s.err) s.augment_all(nf);
             }
         }
@@ -768,17 +869,18 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
             st[10] = s.transfer_rows;
             st[11] = s.arr_iters;
             st[12] = err;
-            st[13] = 0;
-            st[14] = 0;
+            const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+            st[13] = (long long)(t_end - t_start);     // whole kernel, 10 ns ticks
+            st[14] = (long long)(t_serial - t_start);  // greedy + micro-ARR part (SSP branch)
             st[15] = 0;
         }
     }
 }
 
-template <int CH, bool LDS_STATE>
+template <int CH, int LDSL>
 hipError_t launch_one(const SolverParams &p, int threads, size_t lds_bytes, hipStream_t stream)
 {
-    auto kern = jv_instance_kernel<CH, LDS_STATE>;
+    auto kern = jv_instance_kernel<CH, LDSL>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -786,18 +888,27 @@ hipError_t launch_one(const SolverParams &p, int threads, size_t lds_bytes, hipS
     return hipGetLastError();
 }
 
+int batch_depth(int ch) { return ch >= 16 ? 1 : (ch == 8 ? 2 : (ch == 4 ? 4 : 8)); }
+
 }  // namespace
 
-size_t solver_lds_bytes(int n, bool lds_state)
+// level 2: every array in LDS; 1: x and the free-row list in global memory; 0: all global
+size_t solver_lds_bytes(int n, int ch, int level)
 {
     const int W = (n + 31) >> 5;
     const int Wpad = (W + 1) & ~1;
-    size_t bytes = sizeof(BlockExchange) + sizeof(Ctrl) + 3 * sizeof(uint32_t) * (size_t)Wpad;
-    if (lds_state) bytes += (size_t)n * (2 * sizeof(double) + 5 * sizeof(int));
+    size_t bytes = sizeof(BlockExchange) + sizeof(Ctrl) + sizeof(uint32_t) * (size_t)Wpad * (4 + batch_depth(ch));
+    if (level >= 1) bytes += (size_t)n * (2 * sizeof(double) + 4 * sizeof(int));
+    if (level >= 2) bytes += (size_t)n * 2 * sizeof(int);
     return bytes;
 }
 
-bool solver_fits_lds(int n) { return solver_lds_bytes(n, true) <= kLdsBudgetBytes; }
+int solver_lds_level(int n, int ch)
+{
+    if (solver_lds_bytes(n, ch, 2) <= kLdsBudgetBytes) return 2;
+    if (solver_lds_bytes(n, ch, 1) <= kLdsBudgetBytes) return 1;
+    return 0;
+}
 
 // Picks (threads, CH) with threads*CH >= n.  `threads_hint` (0 = auto) lets the bench sweep
 // the geometry; it is rounded to a supported value.
@@ -805,11 +916,12 @@ void solver_geometry(int n, int threads_hint, int *threads, int *ch)
 {
     int t = threads_hint;
     if (t <= 0) {
+        // measured on MI355X (K3, n=2048): 1024 threads 107 ms, 512: 128 ms, 256: 180 ms --
+        // the per-step fixed latency dominates, so use as many lanes as there are columns
         if (n <= 64) t = 64;
-        else if (n <= 256) t = 64;
-        else if (n <= 512) t = 128;
-        else if (n <= 1024) t = 256;
-        else if (n <= 2048) t = 512;
+        else if (n <= 128) t = 128;
+        else if (n <= 256) t = 256;
+        else if (n <= 512) t = 512;
         else t = 1024;
     }
     t = ((t + 63) / 64) * 64;
@@ -824,16 +936,17 @@ void solver_geometry(int n, int threads_hint, int *threads, int *ch)
 
 hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t stream)
 {
-    const bool lds_state = solver_fits_lds(p.n);
     int threads, ch;
     solver_geometry(p.n, threads_hint, &threads, &ch);
     if ((long long)threads * ch < p.n) return hipErrorInvalidValue;  // n > 16384
-    if (!lds_state && !p.g_dist) return hipErrorInvalidValue;
-    const size_t lds = solver_lds_bytes(p.n, lds_state);
+    const int level = solver_lds_level(p.n, ch);
+    if (level < 2 && !p.g_dist) return hipErrorInvalidValue;
+    const size_t lds = solver_lds_bytes(p.n, ch, level);
 #define LAPWARM_CASE(CHV)                                                         \
     case CHV:                                                                     \
-        return lds_state ? launch_one<CHV, true>(p, threads, lds, stream)         \
-                         : launch_one<CHV, false>(p, threads, lds, stream);
+        if (level == 2) return launch_one<CHV, 2>(p, threads, lds, stream);       \
+        if (level == 1) return launch_one<CHV, 1>(p, threads, lds, stream);       \
+        return launch_one<CHV, 0>(p, threads, lds, stream);
     switch (ch) {
         LAPWARM_CASE(1)
         LAPWARM_CASE(2)
@@ -843,6 +956,19 @@ hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t st
     }
 #undef LAPWARM_CASE
     return hipErrorInvalidValue;
+}
+
+bool solver_needs_global_state(int n)
+{
+    int threads, ch;
+    solver_geometry(n, 0, &threads, &ch);
+    int worst = solver_lds_level(n, ch);
+    // a threads_hint may pick another CH: be conservative for every supported geometry
+    for (int c = 1; c <= 16; c <<= 1) {
+        const int l = solver_lds_level(n, c);
+        if (l < worst) worst = l;
+    }
+    return worst < 2;
 }
 
 }  // namespace lapwarm

@@ -40,11 +40,12 @@ struct SolverParams {
     long long *stats;          // [batch][kStatsPerInstance] or null
     // per-instance state in global memory, only used when the state does not fit LDS
     double *g_dist, *g_v;
-    int *g_order, *g_pred, *g_y, *g_x, *g_fr;
+    int *g_order, *g_pred, *g_y, *g_x, *g_fr, *g_pos;
 };
 
-size_t solver_lds_bytes(int n, bool lds_state);
-bool solver_fits_lds(int n);
+size_t solver_lds_bytes(int n, int ch, int level);
+int solver_lds_level(int n, int ch);
+bool solver_needs_global_state(int n);
 void solver_geometry(int n, int threads_hint, int *threads, int *ch);
 hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t stream);
 

@@ -50,7 +50,7 @@ struct SeededWs {
     int *viol_cnt, *tight_cnt, *flags;
     uint32_t *tight_bits;
     double *g_dist, *g_v;
-    int *g_order, *g_pred, *g_y, *g_x, *g_fr;
+    int *g_order, *g_pred, *g_y, *g_x, *g_fr, *g_pos;
     size_t bytes;
 };
 
@@ -67,7 +67,7 @@ SeededWs carve_seeded(void *ws, int batch, int n)
     s.tight_cnt = c.take<int>(bn);
     s.flags = c.take<int>((size_t)batch);
     s.tight_bits = c.take<uint32_t>(bn * W);
-    if (!solver_fits_lds(n)) {
+    if (solver_needs_global_state(n)) {
         s.g_dist = c.take<double>(bn);
         s.g_v = c.take<double>(bn);
         s.g_order = c.take<int>(bn);
@@ -75,9 +75,10 @@ SeededWs carve_seeded(void *ws, int batch, int n)
         s.g_y = c.take<int>(bn);
         s.g_x = c.take<int>(bn);
         s.g_fr = c.take<int>(bn);
+        s.g_pos = c.take<int>(bn);
     } else {
         s.g_dist = s.g_v = nullptr;
-        s.g_order = s.g_pred = s.g_y = s.g_x = s.g_fr = nullptr;
+        s.g_order = s.g_pred = s.g_y = s.g_x = s.g_fr = s.g_pos = nullptr;
     }
     s.bytes = c.off;
     return s;
@@ -246,6 +247,7 @@ int lapwarm_seeded_batched(const double *C, int batch, int n, const double *u_se
     sp.g_y = w.g_y;
     sp.g_x = w.g_x;
     sp.g_fr = w.g_fr;
+    sp.g_pos = w.g_pos;
     HIP_TRY(profile_begin(stream));
     HIP_TRY(launch_solver(sp, threads_hint, stream));
     HIP_TRY(profile_end(stream));
@@ -280,6 +282,7 @@ int lapwarm_lapjv_batched(const double *C, int batch, int n, int *x, int *y, int
     sp.g_y = w.g_y;
     sp.g_x = w.g_x;
     sp.g_fr = w.g_fr;
+    sp.g_pos = w.g_pos;
     HIP_TRY(profile_begin(stream));
     HIP_TRY(launch_solver(sp, threads_hint, stream));
     HIP_TRY(profile_end(stream));

@@ -323,10 +323,8 @@ static int cold_solve(int n, const double *C, int *x, int *y, jvo_stats *st)
     int ret = cold_column_reduction(n, C, free_rows, x, y, v, st);
     for (int sweep = 0; ret > 0 && sweep < 2; ++sweep)
         ret = cold_row_reduction(n, C, (unsigned)ret, free_rows, x, y, v, st);
-    if (ret > 0) {
-        if (st) st->free_rows = ret;
-        ret = sp_augment_all(n, C, ret, free_rows, x, y, v, st);
-    }
+    if (st) st->free_rows = ret; /* rows still free after the ARR sweeps */
+    if (ret > 0) ret = sp_augment_all(n, C, ret, free_rows, x, y, v, st);
     free(v);
     free(free_rows);
     return ret;

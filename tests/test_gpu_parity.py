@@ -160,8 +160,9 @@ def test_batched_k2_counters_match_oracle(torch_cuda):
     from oracle import jv
     B, n = 8, 512
     Cs = np.stack([np.random.RandomState(42 + i).uniform(0, 1, (n, n)) for i in range(B)])
-    us = np.stack([C.min(1) if i % 2 == 0 else np.zeros(n) for i, C in enumerate(Cs)])  # SSP and fallback
-    vs = np.stack([(C - u[:, None]).min(0) for C, u in zip(Cs, us)])
+    # even instances: row-min seeds + fp64 min-trick (SSP branch); odd: zero seeds (fallback branch)
+    us = np.stack([C.min(1) if i % 2 == 0 else np.zeros(n) for i, C in enumerate(Cs)])
+    vs = np.stack([(C - u[:, None]).min(0) if i % 2 == 0 else np.zeros(n) for i, (C, u) in enumerate(zip(Cs, us))])
     pipe = WarmStartPipeline(OneGNN(21), "cuda:0")
     x, y, ret, stats = pipe.seeded_batch(torch.from_numpy(Cs).cuda(), torch.from_numpy(us).cuda(),
                                          torch.from_numpy(vs).cuda())
