@@ -18,6 +18,10 @@ constexpr int kFlagHasViolation = 1;    // some (i,j) has (u_i+v_j)-C_ij > eps u
 constexpr int kFlagInfeasible = 2;      // some (i,j) has (C_ij-u_i)-v_j < -eps (verify step)
 constexpr int kFlagProjected = 4;       // the projection kernel changed (u,v): prelude must be redone
 
+// Keeps a loaded value (and therefore its load) where it is: LLVM otherwise sinks a load into the
+// divergent branch that consumes it, which serialises the memory latencies of a thread's gathers.
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
+
 __device__ __forceinline__ double pos_inf() { return __longlong_as_double(0x7ff0000000000000LL); }
 
 __device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b : a; }
@@ -160,6 +164,29 @@ __device__ __forceinline__ double wave_excl_prefix_min(double x, int lane, doubl
     return (lane == 0) ? pos_inf() : prev;
 }
 
+// Exclusive prefix of the lexicographic (value, index) minimum over the lanes of a wave; lane 0
+// gets (+inf, INT_MAX).  (*tv, *ti) = the wave's total.
+__device__ __forceinline__ void wave_excl_prefix_min_pair(double &v, int &idx, int lane, double *tv, int *ti)
+{
+    double iv = v;
+    int ii = idx;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const double ov = __shfl_up(iv, off, kWave);
+        const int oi = __shfl_up(ii, off, kWave);
+        if (lane >= off && pair_less(ov, oi, iv, ii)) {
+            iv = ov;
+            ii = oi;
+        }
+    }
+    *tv = __shfl(iv, kWave - 1, kWave);
+    *ti = __shfl(ii, kWave - 1, kWave);
+    const double pv = __shfl_up(iv, 1, kWave);
+    const int pi = __shfl_up(ii, 1, kWave);
+    v = (lane == 0) ? pos_inf() : pv;
+    idx = (lane == 0) ? 0x7fffffff : pi;
+}
+
 // ---- workgroup-level exchange through LDS ------------------------------------------------
 // Two alternating slot sets: call k writes set (k&1), one barrier, then reads it.  A thread
 // can only reach the write of call k+2 after the barrier of call k+1, which every reader of
@@ -185,6 +212,8 @@ struct BlockCtx {
         ex = e;
     }
 
+    // Cross-wave combine without a serial LDS loop: lane l reads the slot of wave (l & 15) -- one
+    // LDS round trip -- and a 4-step butterfly over 16 lanes finishes the reduction.
     __device__ __forceinline__ double min_f64(double v)
     {
         v = wave_min(v);
@@ -192,8 +221,20 @@ struct BlockCtx {
         parity ^= 1;
         if (lane == 0) ex->d[p][wave] = v;
         __syncthreads();
-        double r = ex->d[p][0];
-        for (int w = 1; w < nwaves; ++w) r = dmin(r, ex->d[p][w]);
+        const int w = lane & (kMaxWaves - 1);
+        double r = (w < nwaves) ? ex->d[p][w] : pos_inf();
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) r = dmin(r, __shfl_xor(r, m, kWave));
+        return r;
+    }
+
+    // exclusive prefix-min over waves of the per-wave totals (after the caller's own barrier)
+    __device__ __forceinline__ double prefix_min_over_waves(const double *slots) const
+    {
+        const int w = lane & (kMaxWaves - 1);
+        double r = (w < wave) ? slots[w] : pos_inf();
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) r = dmin(r, __shfl_xor(r, m, kWave));
         return r;
     }
 
@@ -232,9 +273,11 @@ struct BlockCtx {
         parity ^= 1;
         if (lane == 0) ex->i[p][wave] = v;
         __syncthreads();
-        int r = ex->i[p][0];
-        for (int w = 1; w < nwaves; ++w) {
-            const int o = ex->i[p][w];
+        const int w = lane & (kMaxWaves - 1);
+        int r = (w < nwaves) ? ex->i[p][w] : 0x7fffffff;
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+            const int o = __shfl_xor(r, m, kWave);
             r = (o < r) ? o : r;
         }
         return r;
@@ -247,8 +290,10 @@ struct BlockCtx {
         parity ^= 1;
         if (lane == 0) ex->i[p][wave] = v;
         __syncthreads();
-        int r = 0;
-        for (int w = 0; w < nwaves; ++w) r += ex->i[p][w];
+        const int w = lane & (kMaxWaves - 1);
+        int r = (w < nwaves) ? ex->i[p][w] : 0;
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) r += __shfl_xor(r, m, kWave);
         return r;
     }
 
@@ -298,17 +343,21 @@ struct BlockCtx {
             ex->i[p][2 * wave + 1] = t.i2;
         }
         __syncthreads();
-        Top2 r;
-        r.a1 = ex->d[p][0];
-        r.a2 = ex->d[p][1];
-        r.i1 = ex->i[p][0];
-        r.i2 = ex->i[p][1];
-        for (int w = 1; w < nwaves; ++w) {
+        const int w = lane & (kMaxWaves - 1);
+        Top2 r = top2_empty();
+        if (w < nwaves) {
+            r.a1 = ex->d[p][2 * w];
+            r.a2 = ex->d[p][2 * w + 1];
+            r.i1 = ex->i[p][2 * w];
+            r.i2 = ex->i[p][2 * w + 1];
+        }
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
             Top2 o;
-            o.a1 = ex->d[p][2 * w];
-            o.a2 = ex->d[p][2 * w + 1];
-            o.i1 = ex->i[p][2 * w];
-            o.i2 = ex->i[p][2 * w + 1];
+            o.a1 = __shfl_xor(r.a1, m, kWave);
+            o.i1 = __shfl_xor(r.i1, m, kWave);
+            o.a2 = __shfl_xor(r.a2, m, kWave);
+            o.i2 = __shfl_xor(r.i2, m, kWave);
             r = top2_merge(r, o);
         }
         return r;

@@ -22,13 +22,15 @@
 //     loops, so event detection on the pre-loop order is exact; random data has ~ln n events.
 //   * the minima collection that follows an event-free relax step reuses the distances that
 //     are still in registers (no second LDS sweep);
-//   * the relax loop is batched: up to SMAX queued SCAN columns (they all sit at the same level)
-//     are relaxed in ONE pass -- every TODO position loads its entry of all their rows, then
-//     replays the serial sequence in registers.  A column's evolution inside the batch depends
-//     on no other column; only the ORDER of the tie events does, and that is rebuilt by wave 0
-//     step by step from per-step column bitmaps and the inverse permutation pos[].  Writes made
-//     by the pass after an early return are unobservable (dist/order die with the path, pred is
-//     only read along READY/SCAN columns), so the pass never has to be rolled back.
+//   * measured on MI355X: the search tree grows as a CHAIN (a relax step typically uncovers
+//     exactly one new tight column), so steps cannot be batched and per-step latency is the
+//     whole game.  Each thread therefore keeps the column, its dual and its distance for the
+//     positions it owns in registers (a relax step is: one global gather, two subtractions, one
+//     compare), and a step with exactly one tie event -- the common case -- is resolved with a
+//     single barrier: the finder publishes (column, position, matched row, displaced column) in
+//     a double-buffered LDS slot, every thread advances the uniform state from it, and only the
+//     owner of the affected position touches order[].  Steps with several events fall back to
+//     the ordered replay by wave 0.
 #include "device_utils.hpp"
 #include "jv_solver.hpp"
 
@@ -36,46 +38,59 @@ namespace lapwarm {
 
 namespace {
 
+struct EventSlot {
+    int j, p, i, a;  // event column, its position, its matched row (-1: free), column at order[hi]
+};
+
 struct Ctrl {
     double level;
-    long long batch_elems;
+    EventSlot slot[2];
     int hi;
     int target;
-    int evt_step;
+    int tie_find;     // sequence number of the last minima collection that saw a tie
+    int ev_total[2];  // monotonic tie-event counters, one per step parity (readers diff them;
+                      // a reader of step t can never see an increment of step t+1)
     int first_fire;
     int nfree;
     int err;
-    unsigned ev_mask;
-    int batch_steps;
-};
-
-template <int CH>
-struct BatchDepth {
-    static constexpr int value = (CH >= 16) ? 1 : (CH == 8 ? 2 : (CH == 4 ? 4 : 8));
+    int head_j, head_i;
 };
 
 constexpr int kSentinelIdx = 0x7ffffffe;  // the LARGE sentinel of the ARR scan (index -1 in the reference)
 constexpr int kEmptyIdx = 0x7fffffff;
 
+#ifdef LAPWARM_STAMPS
+#define STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#define STAMP_ADD(slot, t1, t0) stamps[slot] += (long long)((t1) - (t0))
+#define STAMP_INC(slot) stamps[slot] += 1
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, t1, t0)
+#define STAMP_INC(slot)
+#endif
+
 template <int CH, int LDSL>
 struct Solver {
     static constexpr bool LDS_STATE = LDSL > 0;
-    static constexpr int SMAX = BatchDepth<CH>::value;
     // problem
     const double *C;
     int n, W;
     // state
     double *dist, *v;
-    int *order, *pred, *y, *x, *fr, *pos;
-    uint32_t *evt, *sbits, *used, *evb, *tmpb;
-    int Wpad;
+    int *order, *pred, *y, *x, *fr;
+    uint32_t *evt, *sbits, *used, *evb;
+    int *evlist;  // 64 entries: events of one minima collection, in position order
     Ctrl *ctrl;
     BlockCtx bc;
     // uniform counters (identical in every thread)
     long long scan_elems, init_elems, colred_elems;
     int paths, finds, scan_steps, arr_iters, transfer_rows, arr_fired;
     int step_id;
+    int ctrl_seen0, ctrl_seen1, ctrl_find_seq;
     int err;
+#ifdef LAPWARM_STAMPS
+    long long stamps[16];
+#endif
 
     __device__ __forceinline__ int base() const { return bc.tid * CH; }
 
@@ -86,42 +101,121 @@ struct Solver {
 
     // ------------------------------------------------------------------ event replay (wave 0)
     // Minima collection, lapjv.cpp:153-171, given the event / strict bitmaps.
+    //
+    // Fast path (at most 64 events, the usual case): the serial swap sequence touches only the
+    // event positions and the slots order[lo .. lo+m).  Wave 0 keeps those 64 slots as one value
+    // per lane ("window"), gathers the event columns in parallel -- order[e_i] cannot have been
+    // modified before its own turn, because every earlier target slot is < lo+i <= e_i -- and
+    // replays the swaps with readlane/writelane (no LDS round trip per event).  Larger event
+    // counts take the LDS loop below.
     __device__ __forceinline__ void replay_find(int lo)
     {
         const int lane = bc.lane;
         int hi = lo + 1;
+#ifdef LAPWARM_STAMPS
+        int n_events = 0;
+#endif
+        // ---- gather the events in position order
+        int total = 0;
         for (int wbase = 0; wbase < W; wbase += kWave) {
             const int idx = wbase + lane;
-            uint32_t ew = 0, sw = 0;
-            if (idx < W) {
-                ew = evt[idx];
-                sw = sbits[idx];
-                if (ew) {
-                    evt[idx] = 0;
-                    sbits[idx] = 0;
-                }
-            }
-            unsigned long long mask = __ballot(ew != 0);
-            while (mask) {
-                const int l = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                uint32_t e = __shfl(ew, l, kWave);
-                const uint32_t s = __shfl(sw, l, kWave);
-                while (e) {
-                    const int bit = __builtin_ctz(e);
-                    e &= e - 1;
-                    const int k = ((wbase + l) << 5) + bit;
-                    const int j = order[k];
-                    if ((s >> bit) & 1u) hi = lo;
-                    const int a = order[hi];
-                    if (lane == 0) {
-                        order[k] = a;
-                        pos[a] = k;
-                        order[hi] = j;
-                        pos[j] = hi;
+            const uint32_t ew = (idx < W) ? evt[idx] : 0u;
+            total += wave_sum_i32(__popc(ew));
+        }
+#ifdef LAPWARM_STAMPS
+        n_events = total;
+#endif
+        if (total <= kWave) {
+            int base_cnt = 0;
+            for (int wbase = 0; wbase < W; wbase += kWave) {
+                const int idx = wbase + lane;
+                uint32_t ew = 0, sw = 0;
+                if (idx < W) {
+                    ew = evt[idx];
+                    sw = sbits[idx];
+                    if (ew) {
+                        evt[idx] = 0;
+                        sbits[idx] = 0;
                     }
-                    fence_if_global();
-                    ++hi;
+                }
+                const int mine = __popc(ew);
+                int incl = mine;
+#pragma unroll
+                for (int off = 1; off < kWave; off <<= 1) {
+                    const int o = __shfl_up(incl, off, kWave);
+                    if (lane >= off) incl += o;
+                }
+                int slot = base_cnt + incl - mine;
+                while (ew) {
+                    const int bit = __builtin_ctz(ew);
+                    ew &= ew - 1;
+                    evlist[slot++] = ((idx << 5) + bit) | (int)(((sw >> bit) & 1u) << 31);
+                }
+                base_cnt += __shfl(incl, kWave - 1, kWave);
+            }
+            // lane i owns event i
+            int kv = 0, cv = 0;
+            if (lane < total) {
+                kv = evlist[lane];
+                cv = order[kv & 0x7fffffff];
+            }
+            int win = (lo + lane < n) ? order[lo + lane] : 0;
+            int outv = 0;
+            int used_slots = 1;
+            for (int i = 0; i < total; ++i) {
+                const int ki = __builtin_amdgcn_readlane(kv, i);
+                const int c = __builtin_amdgcn_readlane(cv, i);
+                const int pos = ki & 0x7fffffff;
+                if (ki < 0) hi = lo;  // strict event
+                const int q = hi - lo;
+                const int a = __builtin_amdgcn_readlane(win, q);
+                win = (lane == q) ? c : win;
+                const int rel = pos - lo;
+                if (rel < kWave)
+                    win = (lane == rel) ? a : win;
+                else
+                    outv = (lane == i) ? a : outv;
+                ++hi;
+                if (q + 1 > used_slots) used_slots = q + 1;
+            }
+            // write back: the window slots and the out-of-window event positions
+            if (total > 0) {
+                if (lo + lane < n) order[lo + lane] = win;
+                if (lane < total && (kv & 0x7fffffff) - lo >= kWave) order[kv & 0x7fffffff] = outv;
+            }
+            fence_if_global();
+        } else {
+            for (int wbase = 0; wbase < W; wbase += kWave) {
+                const int idx = wbase + lane;
+                uint32_t ew = 0, sw = 0;
+                if (idx < W) {
+                    ew = evt[idx];
+                    sw = sbits[idx];
+                    if (ew) {
+                        evt[idx] = 0;
+                        sbits[idx] = 0;
+                    }
+                }
+                unsigned long long mask = __ballot(ew != 0);
+                while (mask) {
+                    const int l = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    uint32_t e = __shfl(ew, l, kWave);
+                    const uint32_t s = __shfl(sw, l, kWave);
+                    while (e) {
+                        const int bit = __builtin_ctz(e);
+                        e &= e - 1;
+                        const int k = ((wbase + l) << 5) + bit;
+                        const int j = order[k];
+                        if ((s >> bit) & 1u) hi = lo;
+                        const int a = order[hi];
+                        if (lane == 0) {
+                            order[k] = a;
+                            order[hi] = j;
+                        }
+                        fence_if_global();
+                        ++hi;
+                    }
                 }
             }
         }
@@ -137,88 +231,56 @@ struct Solver {
         }
         const int target = (best >= 0) ? order[best] : -1;
         const double level = dist[order[lo]];
+        const int head_j = order[lo];
+        const int head_i = y[head_j];
         if (lane == 0) {
             ctrl->hi = hi;
             ctrl->target = target;
             ctrl->level = level;
+            ctrl->head_j = head_j;
+            ctrl->head_i = head_i;
         }
     }
 
-    // Tie events of one batch of relax steps (lapjv.cpp:199-205), replayed step by step.
-    // evb[s] holds, per COLUMN, the events the pass found at step s; their order inside a step
-    // is the order of the columns' positions at that step's start, read from pos[].
-    __device__ __forceinline__ void replay_batch(int hi, int S)
+    // Several tie events in one relax step (lapjv.cpp:199-205): replay them in position order.
+    __device__ __forceinline__ void replay_scan(int hi)
     {
         const int lane = bc.lane;
-        const unsigned mask = ctrl->ev_mask;
         int target = -1;
-        long long elems = 0;
-        int steps = 0;
-        for (int st = 0; st < S && target < 0; ++st) {
-            elems += (long long)(n - hi);
-            ++steps;
-            if (!((mask >> st) & 1u)) continue;
-            uint32_t *eb = evb + (size_t)st * Wpad;
-            for (int wbase = 0; wbase < W; wbase += kWave) {
-                const int idx = wbase + lane;
-                uint32_t word = 0;
-                if (idx < W) {
-                    word = eb[idx];
-                    if (word) eb[idx] = 0;
-                }
-                while (word) {
-                    const int bit = __builtin_ctz(word);
-                    word &= word - 1;
-                    const int p = pos[(idx << 5) + bit];
-                    atomicOr(&tmpb[p >> 5], 1u << (p & 31));
-                }
+        for (int wbase = 0; wbase < W; wbase += kWave) {
+            const int idx = wbase + lane;
+            uint32_t ew = 0;
+            if (idx < W) {
+                ew = evb[idx];
+                if (ew) evb[idx] = 0;
             }
-            fence_if_global();
-            for (int wbase = 0; wbase < W; wbase += kWave) {
-                const int idx = wbase + lane;
-                uint32_t tw = 0;
-                if (idx < W) {
-                    tw = tmpb[idx];
-                    if (tw) tmpb[idx] = 0;
-                }
-                unsigned long long m = __ballot(tw != 0);
-                while (m && target < 0) {
-                    const int l = __builtin_ctzll(m);
-                    m &= m - 1;
-                    uint32_t e = __shfl(tw, l, kWave);
-                    while (e && target < 0) {
-                        const int bit = __builtin_ctz(e);
-                        e &= e - 1;
-                        const int p = ((wbase + l) << 5) + bit;
-                        const int j = order[p];
-                        if (y[j] < 0) {
-                            target = j;
-                        } else {
-                            const int a = order[hi];
-                            if (lane == 0) {
-                                order[p] = a;
-                                pos[a] = p;
-                                order[hi] = j;
-                                pos[j] = hi;
-                            }
-                            fence_if_global();
-                            ++hi;
+            unsigned long long mask = __ballot(ew != 0);
+            while (mask && target < 0) {
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                uint32_t e = __shfl(ew, l, kWave);
+                while (e && target < 0) {
+                    const int bit = __builtin_ctz(e);
+                    e &= e - 1;
+                    const int k = ((wbase + l) << 5) + bit;
+                    const int j = order[k];
+                    if (y[j] < 0) {
+                        target = j;
+                    } else {
+                        const int a = order[hi];
+                        if (lane == 0) {
+                            order[k] = a;
+                            order[hi] = j;
                         }
+                        fence_if_global();
+                        ++hi;
                     }
                 }
             }
         }
-        if (target >= 0) {
-            // early return: drop whatever is still queued in the bitmaps
-            for (int w = lane; w < Wpad; w += kWave) tmpb[w] = 0;
-            for (int w = lane; w < SMAX * Wpad; w += kWave) evb[w] = 0;
-        }
         if (lane == 0) {
             ctrl->hi = hi;
             ctrl->target = target;
-            ctrl->ev_mask = 0;
-            ctrl->batch_elems = elems;
-            ctrl->batch_steps = steps;
         }
     }
 
@@ -228,27 +290,47 @@ struct Solver {
     {
         const int b0 = base();
         const int wordi = b0 >> 5, shift = b0 & 31;
-        double dk[CH];
+        STAMP(tpath);
+        // the duals of the owned columns are cached in registers while the budget allows
+        // (1024-thread workgroups cap a thread at 128 VGPRs)
+        constexpr bool CACHE_V = CH <= 4;
+        double dk[CH], vr[CACHE_V ? CH : 1];
+        int jr[CH];
         {
+            // every load is issued before the first use: indices are clamped instead of
+            // branching, so the CH gathers of a thread are all in flight together
             const double *row = C + (size_t)start * n;
+            double c0[CH];
 #pragma unroll
             for (int r = 0; r < CH; ++r) {
                 const int k = b0 + r;
+                jr[r] = (k < n) ? k : n - 1;
+                c0[r] = row[jr[r]];
+            }
+#pragma unroll
+            for (int r = 0; r < CH; ++r) pin(c0[r]);
+#pragma unroll
+            for (int r = 0; r < CH; ++r) {
+                const int k = b0 + r;
+                const double vk = v[jr[r]];
+                if constexpr (CACHE_V) vr[r] = vk;
+                const double val = c0[r] - vk;
+                dk[r] = (k < n) ? val : pos_inf();
                 if (k < n) {
-                    const double val = row[k] - v[k];
                     order[k] = k;
-                    pos[k] = k;
                     pred[k] = start;
                     dist[k] = val;
-                    dk[r] = val;
-                } else {
-                    dk[r] = pos_inf();
                 }
             }
         }
         paths++;
         init_elems += n;
         int lo = 0, hi = 0, ready = 0, target = -1;
+        int head_j = 0, head_i = 0;
+        STAMP(tp0);
+        STAMP_ADD(8, tp0, tpath);
+        int seen0 = ctrl_seen0, seen1 = ctrl_seen1;
+        int find_seq = ctrl_find_seq;
         double level = 0.0;
         int guard = 0;
         while (target < 0) {
@@ -257,121 +339,303 @@ struct Solver {
                 break;
             }
             if (lo == hi) {
-                // ---------------- minima collection over positions [lo, n); dk[] is current
+                // ---------------- minima collection over positions [lo, n); dk[] is current.
+                // Scan of the lexicographic (distance, position) minimum = "the first position that
+                // holds the running minimum".  A position is a STRICT event when it undercuts the
+                // minimum of everything before it, a TIE event when it equals it.  Without tie
+                // events the serial swap sequence (lapjv.cpp:158-168) collapses to a shift: every
+                // event position receives the column of the previous record holder and slot lo
+                // receives the final minimum -- applied here by the event owners themselves, no
+                // ordered replay.  Any tie anywhere sends the whole collection to the exact replay.
+                STAMP(tf0);
                 ready = lo;
-                double tmin = pos_inf();
+                ++find_seq;
+                double tv = pos_inf();
+                int tp = 0x7fffffff;
 #pragma unroll
                 for (int r = 0; r < CH; ++r) {
                     const int k = b0 + r;
-                    if (k >= lo && k < n) tmin = dmin(tmin, dk[r]);
-                }
-                double wtot;
-                double run = wave_excl_prefix_min(tmin, bc.lane, &wtot);
-                {
-                    const int p = bc.parity;
-                    bc.parity ^= 1;
-                    if (bc.lane == 0) bc.ex->d[p][bc.wave] = wtot;
-                    __syncthreads();
-                    for (int w = 0; w < bc.wave; ++w) run = dmin(run, bc.ex->d[p][w]);
-                }
-                uint32_t eb = 0, sb = 0;
-#pragma unroll
-                for (int r = 0; r < CH; ++r) {
-                    const int k = b0 + r;
-                    if (k >= lo && k < n) {
-                        if (k > lo && dk[r] <= run) {
-                            eb |= 1u << r;
-                            if (dk[r] < run) sb |= 1u << r;
-                        }
-                        run = dmin(run, dk[r]);
+                    // position lo always starts as the holder, whatever its value (even +inf)
+                    if (k >= lo && k < n && (k == lo || dk[r] < tv)) {
+                        tv = dk[r];
+                        tp = k;
                     }
                 }
-                if (eb) {
-                    atomicOr(&evt[wordi], eb << shift);
-                    if (sb) atomicOr(&sbits[wordi], sb << shift);
+                double runv = tv, wtv;
+                int runp = tp, wtp;
+                wave_excl_prefix_min_pair(runv, runp, bc.lane, &wtv, &wtp);
+                const int xp = bc.parity;
+                bc.parity ^= 1;
+                if (bc.lane == 0) {
+                    bc.ex->d[xp][bc.wave] = wtv;
+                    bc.ex->i[xp][bc.wave] = wtp;
                 }
+                STAMP(tfa);
+                STAMP_ADD(9, tfa, tf0);
                 __syncthreads();
-                if (bc.wave == 0) replay_find(lo);
-                __syncthreads();
-                hi = ctrl->hi;
-                target = ctrl->target;
-                level = ctrl->level;
-                finds++;
-                if (target >= 0) break;
-            }
-            // ---------------- relax a batch of queued SCAN columns (lapjv.cpp:178-213)
-            const int S = (hi - lo < SMAX) ? hi - lo : SMAX;
-            const double *rows[SMAX];
-            double hs[SMAX];
-            int is[SMAX];
+                STAMP(tfb);
+                STAMP_ADD(10, tfb, tfa);
+                double totv;
+                int totp;
+                {
+                    // one LDS round trip: lane l reads the slot of wave (l & 15); a 16-lane
+                    // butterfly gives the block total and the prefix over the earlier waves
+                    const int w = bc.lane & (kMaxWaves - 1);
+                    const double sv = (w < bc.nwaves) ? bc.ex->d[xp][w] : pos_inf();
+                    const int sp = (w < bc.nwaves) ? bc.ex->i[xp][w] : 0x7fffffff;
+                    double av = sv, pv = (w < bc.wave) ? sv : pos_inf();
+                    int ap = sp, pp = (w < bc.wave) ? sp : 0x7fffffff;
 #pragma unroll
-            for (int q = 0; q < SMAX; ++q) {
-                rows[q] = C;
-                hs[q] = 0.0;
-                is[q] = 0;
-                if (q < S) {
-                    const int jc = order[lo + q];
-                    const int i = y[jc];
-                    is[q] = i;
-                    rows[q] = C + (size_t)i * n;
-                    hs[q] = (rows[q][jc] - v[jc]) - level;
+                    for (int m = 8; m >= 1; m >>= 1) {
+                        const double o1 = __shfl_xor(av, m, kWave);
+                        const int o2 = __shfl_xor(ap, m, kWave);
+                        if (pair_less(o1, o2, av, ap)) {
+                            av = o1;
+                            ap = o2;
+                        }
+                        const double o3 = __shfl_xor(pv, m, kWave);
+                        const int o4 = __shfl_xor(pp, m, kWave);
+                        if (pair_less(o3, o4, pv, pp)) {
+                            pv = o3;
+                            pp = o4;
+                        }
+                    }
+                    totv = av;
+                    totp = ap;
+                    if (pair_less(pv, pp, runv, runp)) {
+                        runv = pv;
+                        runp = pp;
+                    }
                 }
+                STAMP(tfc);
+                // classify the owned positions; remember what each strict event receives
+                uint32_t eb = 0, sb = 0;
+                bool tie = false;
+                int prevpos[CH];
+                double prevval[CH];
+#pragma unroll
+                for (int r = 0; r < CH; ++r) {
+                    const int k = b0 + r;
+                    prevpos[r] = -1;
+                    prevval[r] = 0.0;
+                    if (k >= lo && k < n) {
+                        if (k > lo && dk[r] <= runv) {
+                            eb |= 1u << r;
+                            if (dk[r] < runv) {
+                                sb |= 1u << r;
+                                prevpos[r] = runp;
+                                prevval[r] = runv;
+                            } else {
+                                tie = true;
+                            }
+                        }
+                        if (k == lo || dk[r] < runv) {
+                            runv = dk[r];
+                            runp = k;
+                        }
+                    }
+                }
+                int prevcol[CH];
+#pragma unroll
+                for (int r = 0; r < CH; ++r) prevcol[r] = (prevpos[r] >= 0) ? order[prevpos[r]] : 0;
+                const int min_col = order[totp];  // column of the global minimum (uniform)
+                if (tie) ctrl->tie_find = find_seq;
+                STAMP(tfd);
+                STAMP_ADD(11, tfd, tfc);
+                __syncthreads();
+                STAMP(tfe);
+                STAMP_ADD(12, tfe, tfd);
+                finds++;
+                if (ctrl->tie_find != find_seq) {
+                    // ---- tie-free: apply the shift locally
+#pragma unroll
+                    for (int r = 0; r < CH; ++r) {
+                        if (sb & (1u << r)) {
+                            const int k = b0 + r;
+                            order[k] = prevcol[r];
+                            jr[r] = prevcol[r];
+                            dk[r] = prevval[r];
+                            if constexpr (CACHE_V) vr[r] = v[prevcol[r]];
+                        }
+                    }
+                    if (totp != lo && lo >= b0 && lo < b0 + CH) order[lo] = min_col;
+                    hi = lo + 1;
+                    level = totv;
+                    head_j = min_col;
+                    head_i = y[min_col];
+                    target = (head_i < 0) ? head_j : -1;
+                    STAMP(tff);
+                    STAMP_ADD(13, tff, tfe);
+                    if (target >= 0) break;
+                } else {
+                    // ---- ties: exact ordered replay by wave 0 (bitmaps are only built here)
+                    if (eb) {
+                        atomicOr(&evt[wordi], eb << shift);
+                        if (sb) atomicOr(&sbits[wordi], sb << shift);
+                    }
+                    __syncthreads();
+                    if (bc.wave == 0) replay_find(lo);
+                    __syncthreads();
+                    hi = ctrl->hi;
+                    target = ctrl->target;
+                    level = ctrl->level;
+                    head_j = ctrl->head_j;
+                    head_i = ctrl->head_i;
+                    STAMP(tfg);
+                    STAMP_ADD(14, tfg, tfe);
+                    STAMP_INC(15);
+                    if (target >= 0) break;
+                    // the collection permuted order[]: rebind the registers of the positions we own
+#pragma unroll
+                    for (int r = 0; r < CH; ++r) {
+                        const int k = b0 + r;
+                        if (k >= hi && k < n) {
+                            const int j = order[k];
+                            jr[r] = j;
+                            if constexpr (CACHE_V) vr[r] = v[j];
+                            dk[r] = dist[j];
+                        }
+                    }
+                }
+                STAMP(tf1);
+                STAMP_ADD(0, tf1, tf0);
             }
-            unsigned my_mask = 0;
+            // ---------------- relax the head of the SCAN list (lapjv.cpp:185-207)
+            STAMP(tr0);
+            const double *row = C + (size_t)head_i * n;
+            double c[CH];
+#pragma unroll
+            for (int r = 0; r < CH; ++r) c[r] = row[jr[r]];  // unconditional: all gathers in flight
+            double c_head = row[head_j];
+#pragma unroll
+            for (int r = 0; r < CH; ++r) pin(c[r]);
+            pin(c_head);
+            STAMP(tr1);
+            STAMP_ADD(1, tr1, tr0);
+            const double h = (c_head - v[head_j]) - level;
+            const int par = step_id & 1;
+            int my_events = 0, ev_r = -1;
 #pragma unroll
             for (int r = 0; r < CH; ++r) {
                 const int k = b0 + r;
                 if (k >= hi && k < n) {
-                    const int j = order[k];
-                    double c[SMAX];
-#pragma unroll
-                    for (int q = 0; q < SMAX; ++q) c[q] = (q < S) ? rows[q][j] : 0.0;
-                    const double vj = v[j];
-                    double dj = dist[j];
-                    int pj = -1, ev = -1;
-#pragma unroll
-                    for (int q = 0; q < SMAX; ++q) {
-                        if (q < S && ev < 0) {
-                            const double cand = (c[q] - vj) - hs[q];
-                            if (cand < dj) {
-                                dj = cand;
-                                pj = is[q];
-                                if (cand == level) ev = q;
-                            }
+                    double vj;
+                    if constexpr (CACHE_V)
+                        vj = vr[r];
+                    else
+                        vj = v[jr[r]];
+                    const double cand = (c[r] - vj) - h;
+                    if (cand < dk[r]) {
+                        dk[r] = cand;
+                        dist[jr[r]] = cand;
+                        pred[jr[r]] = head_i;
+                        if (cand == level) {
+                            if (ev_r < 0) ev_r = r;
+                            ++my_events;
+                            atomicOr(&evb[k >> 5], 1u << (k & 31));
                         }
-                    }
-                    if (pj >= 0) {
-                        dist[j] = dj;
-                        pred[j] = pj;
-                    }
-                    dk[r] = dj;
-                    if (ev >= 0) {
-                        atomicOr(&evb[(size_t)ev * Wpad + (j >> 5)], 1u << (j & 31));
-                        my_mask |= 1u << ev;
                     }
                 } else {
                     dk[r] = pos_inf();
                 }
             }
-            if (my_mask) {
-                atomicOr(&ctrl->ev_mask, my_mask);
-                ctrl->evt_step = step_id;
+            const int seen = par ? seen1 : seen0;
+            if (my_events) {
+                const int old = atomicAdd(&ctrl->ev_total[par], my_events);
+                if (old == seen) {
+                    int ej = 0;
+#pragma unroll
+                    for (int r = 0; r < CH; ++r)
+                        if (r == ev_r) ej = jr[r];
+                    EventSlot sl;
+                    sl.j = ej;
+                    sl.p = b0 + ev_r;
+                    sl.i = y[ej];
+                    sl.a = order[hi];
+                    ctrl->slot[par] = sl;
+                }
             }
+            STAMP(tr2);
+            STAMP_ADD(2, tr2, tr1);
             __syncthreads();
-            if (ctrl->evt_step == step_id) {
-                if (bc.wave == 0) replay_batch(hi, S);
+            STAMP(tr3);
+            STAMP_ADD(3, tr3, tr2);
+            const int tot = ctrl->ev_total[par];
+            const int cnt = tot - seen;
+            if (par)
+                seen1 = tot;
+            else
+                seen0 = tot;
+            scan_steps++;
+            scan_elems += (long long)(n - hi);
+            step_id++;
+            if (cnt == 0) {
+                STAMP_INC(5);
+                ++lo;
+                if (lo != hi) {
+                    head_j = order[lo];
+                    head_i = y[head_j];
+                }
+            } else if (cnt == 1) {
+                STAMP_INC(6);
+                const EventSlot sl = ctrl->slot[par];
+                if (sl.p >= b0 && sl.p < b0 + CH) {
+                    // we own the event position: it now holds the column displaced from order[hi]
+                    evb[sl.p >> 5] = 0;  // the only bit set in this step
+                    if (sl.i >= 0) {
+                        const double va = v[sl.a], da = dist[sl.a];
+#pragma unroll
+                        for (int r = 0; r < CH; ++r) {
+                            if (b0 + r == sl.p) {
+                                jr[r] = sl.a;
+                                if constexpr (CACHE_V) vr[r] = va;
+                                dk[r] = da;
+                            }
+                        }
+                        order[sl.p] = sl.a;
+                        order[hi] = sl.j;
+                    }
+                }
+                if (sl.i < 0) {
+                    target = sl.j;
+                    break;
+                }
+                ++hi;
+                ++lo;
+                if (lo == hi - 1) {
+                    head_j = sl.j;
+                    head_i = sl.i;
+                } else {
+                    head_j = order[lo];
+                    head_i = y[head_j];
+                }
+            } else {
+                STAMP_INC(7);
+                if (bc.wave == 0) replay_scan(hi);
                 __syncthreads();
                 hi = ctrl->hi;
                 target = ctrl->target;
-                scan_steps += ctrl->batch_steps;
-                scan_elems += ctrl->batch_elems;
-            } else {
-                scan_steps += S;
-                scan_elems += (long long)S * (n - hi);
+                if (target >= 0) break;
+                ++lo;
+                head_j = order[lo];
+                head_i = y[head_j];
+#pragma unroll
+                for (int r = 0; r < CH; ++r) {
+                    const int k = b0 + r;
+                    if (k >= hi && k < n) {
+                        const int j = order[k];
+                        jr[r] = j;
+                        if constexpr (CACHE_V) vr[r] = v[j];
+                        dk[r] = dist[j];
+                    }
+                }
             }
-            step_id++;
-            lo += S;
+            STAMP(tr4);
+            STAMP_ADD(4, tr4, tr3);
         }
+        ctrl_seen0 = seen0;
+        ctrl_seen1 = seen1;
+        ctrl_find_seq = find_seq;
         // dual update for the READY columns (lapjv.cpp:270-276): v[j] += d[j] - level
 #pragma unroll
         for (int r = 0; r < CH; ++r) {
@@ -419,17 +683,43 @@ struct Solver {
             vm[r] = kLarge;
             ya[r] = 0;
         }
-        for (int i = 0; i < n; ++i) {
+        int jc[CH];
+#pragma unroll
+        for (int r = 0; r < CH; ++r) jc[r] = (b0 + r < n) ? b0 + r : n - 1;
+        constexpr int RU = (CH <= 2) ? 8 : ((CH <= 4) ? 4 : 2);  // rows in flight per thread
+        int i = 0;
+        for (; i + RU <= n; i += RU) {
+            double c[RU][CH];
+#pragma unroll
+            for (int q = 0; q < RU; ++q) {
+                const double *row = C + (size_t)(i + q) * n;
+#pragma unroll
+                for (int r = 0; r < CH; ++r) c[q][r] = row[jc[r]];
+            }
+#pragma unroll
+            for (int q = 0; q < RU; ++q) {
+#pragma unroll
+                for (int r = 0; r < CH; ++r) pin(c[q][r]);
+            }
+#pragma unroll
+            for (int q = 0; q < RU; ++q) {
+#pragma unroll
+                for (int r = 0; r < CH; ++r) {
+                    if (c[q][r] < vm[r]) {
+                        vm[r] = c[q][r];
+                        ya[r] = i + q;
+                    }
+                }
+            }
+        }
+        for (; i < n; ++i) {
             const double *row = C + (size_t)i * n;
 #pragma unroll
             for (int r = 0; r < CH; ++r) {
-                const int j = b0 + r;
-                if (j < n) {
-                    const double c = row[j];
-                    if (c < vm[r]) {
-                        vm[r] = c;
-                        ya[r] = i;
-                    }
+                const double c = row[jc[r]];
+                if (c < vm[r]) {
+                    vm[r] = c;
+                    ya[r] = i;
                 }
             }
         }
@@ -472,13 +762,16 @@ struct Solver {
             } else if (pred[i] == 1) {
                 const double *row = C + (size_t)i * n;
                 double m = kLarge;
+                double ct[CH];
+#pragma unroll
+                for (int r = 0; r < CH; ++r) ct[r] = row[jc[r]];
+#pragma unroll
+                for (int r = 0; r < CH; ++r) pin(ct[r]);
 #pragma unroll
                 for (int r = 0; r < CH; ++r) {
                     const int j2 = b0 + r;
-                    if (j2 < n && j2 != xi) {
-                        const double c = row[j2] - v[j2];
-                        if (c < m) m = c;
-                    }
+                    const double c = ct[r] - v[jc[r]];
+                    if (j2 < n && j2 != xi && c < m) m = c;
                 }
                 m = bc.min_f64(m);
                 if (xi >= b0 && xi < b0 + CH) v[xi] -= m;  // owner thread only
@@ -514,14 +807,16 @@ struct Solver {
             Top2 t = top2_empty();
             if (bc.tid == 0) top2_push(t, kLarge, kSentinelIdx);
 #pragma unroll
+            for (int r = 0; r < CH; ++r) cs[r] = row[(b0 + r < n) ? b0 + r : n - 1];
+#pragma unroll
+            for (int r = 0; r < CH; ++r) pin(cs[r]);
+#pragma unroll
             for (int r = 0; r < CH; ++r) {
                 const int j = b0 + r;
-                cs[r] = pos_inf();
-                if (j < n) {
-                    cs[r] = row[j] - v[j];
-                    if (j == 0) c0 = cs[r];
-                    if (j == 0 || cs[r] < kLarge) top2_push(t, cs[r], j);
-                }
+                const double cv = cs[r] - v[(j < n) ? j : n - 1];
+                cs[r] = (j < n) ? cv : pos_inf();
+                if (j == 0) c0 = cv;
+                if (j < n && (j == 0 || cv < kLarge)) top2_push(t, cv, j);
             }
             t = bc.top2_bcast(t, &c0);
             if (c0 <= kLarge) {
@@ -709,8 +1004,6 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
     const int Wpad = (W + 1) & ~1;
 
     Solver<CH, LDSL> s;
-    constexpr int SMAX = BatchDepth<CH>::value;
-    s.Wpad = Wpad;
     unsigned char *cur = smem;
     BlockExchange *ex = reinterpret_cast<BlockExchange *>(cur);
     cur += sizeof(BlockExchange);
@@ -722,10 +1015,10 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
     cur += sizeof(uint32_t) * Wpad;
     s.used = reinterpret_cast<uint32_t *>(cur);
     cur += sizeof(uint32_t) * Wpad;
-    s.tmpb = reinterpret_cast<uint32_t *>(cur);
-    cur += sizeof(uint32_t) * Wpad;
     s.evb = reinterpret_cast<uint32_t *>(cur);
-    cur += sizeof(uint32_t) * Wpad * SMAX;
+    cur += sizeof(uint32_t) * Wpad;
+    s.evlist = reinterpret_cast<int *>(cur);
+    cur += sizeof(int) * kWave;
     if constexpr (LDSL > 0) {
         s.dist = reinterpret_cast<double *>(cur);
         cur += sizeof(double) * n;
@@ -736,8 +1029,6 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
         s.pred = reinterpret_cast<int *>(cur);
         cur += sizeof(int) * n;
         s.y = reinterpret_cast<int *>(cur);
-        cur += sizeof(int) * n;
-        s.pos = reinterpret_cast<int *>(cur);
         cur += sizeof(int) * n;
         if constexpr (LDSL > 1) {
             s.x = reinterpret_cast<int *>(cur);
@@ -757,7 +1048,6 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
         s.y = p.g_y + o;
         s.x = p.g_x + o;
         s.fr = p.g_fr + o;
-        s.pos = p.g_pos + o;
     }
     s.bc.init(ex);
     s.C = p.C + (size_t)b * n * n;
@@ -766,6 +1056,11 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
     s.scan_elems = s.init_elems = s.colred_elems = 0;
     s.paths = s.finds = s.scan_steps = s.arr_iters = s.transfer_rows = s.arr_fired = 0;
     s.step_id = 1;
+    s.ctrl_seen0 = s.ctrl_seen1 = 0;
+    s.ctrl_find_seq = 0;
+#ifdef LAPWARM_STAMPS
+    for (int q = 0; q < 16; ++q) s.stamps[q] = 0;
+#endif
     s.err = 0;
 
     const int tid = s.bc.tid;
@@ -783,22 +1078,22 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
     }
 
     if (tid == 0) {
-        s.ctrl->evt_step = 0;
+        s.ctrl->tie_find = 0;
+        s.ctrl->ev_total[0] = 0;
+        s.ctrl->ev_total[1] = 0;
         s.ctrl->err = 0;
         s.ctrl->nfree = 0;
         s.ctrl->hi = 0;
         s.ctrl->target = -1;
-        s.ctrl->ev_mask = 0;
-        s.ctrl->batch_steps = 0;
-        s.ctrl->batch_elems = 0;
+        s.ctrl->head_j = 0;
+        s.ctrl->head_i = 0;
     }
     for (int w = tid; w < Wpad; w += blockDim.x) {
         s.evt[w] = 0;
         s.sbits[w] = 0;
         s.used[w] = 0;
-        s.tmpb[w] = 0;
+        s.evb[w] = 0;
     }
-    for (int w = tid; w < Wpad * SMAX; w += blockDim.x) s.evb[w] = 0;
     int tight_local = 0;
     for (int j = tid; j < n; j += blockDim.x) {
         s.x[j] = -1;
@@ -873,6 +1168,10 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
             st[13] = (long long)(t_end - t_start);     // whole kernel, 10 ns ticks
             st[14] = (long long)(t_serial - t_start);  // greedy + micro-ARR part (SSP branch)
             st[15] = 0;
+            for (int q = 16; q < kStatsPerInstance; ++q) st[q] = 0;
+#ifdef LAPWARM_STAMPS
+            for (int q = 0; q < 16; ++q) st[16 + q] = s.stamps[q];
+#endif
         }
     }
 }
@@ -888,8 +1187,6 @@ hipError_t launch_one(const SolverParams &p, int threads, size_t lds_bytes, hipS
     return hipGetLastError();
 }
 
-int batch_depth(int ch) { return ch >= 16 ? 1 : (ch == 8 ? 2 : (ch == 4 ? 4 : 8)); }
-
 }  // namespace
 
 // level 2: every array in LDS; 1: x and the free-row list in global memory; 0: all global
@@ -897,8 +1194,9 @@ size_t solver_lds_bytes(int n, int ch, int level)
 {
     const int W = (n + 31) >> 5;
     const int Wpad = (W + 1) & ~1;
-    size_t bytes = sizeof(BlockExchange) + sizeof(Ctrl) + sizeof(uint32_t) * (size_t)Wpad * (4 + batch_depth(ch));
-    if (level >= 1) bytes += (size_t)n * (2 * sizeof(double) + 4 * sizeof(int));
+    (void)ch;
+    size_t bytes = sizeof(BlockExchange) + sizeof(Ctrl) + sizeof(uint32_t) * (size_t)Wpad * 4 + sizeof(int) * kWave;
+    if (level >= 1) bytes += (size_t)n * (2 * sizeof(double) + 3 * sizeof(int));
     if (level >= 2) bytes += (size_t)n * 2 * sizeof(int);
     return bytes;
 }

@@ -17,7 +17,7 @@ constexpr int kBranchAllMatched = 2;
 constexpr int kBranchFallback = 3;
 constexpr int kBranchCold = 4;
 
-constexpr int kStatsPerInstance = 16;
+constexpr int kStatsPerInstance = 32;  // 0..15 counters, 16..31 cycle stamps (diagnostic builds)
 constexpr size_t kLdsBudgetBytes = 160 * 1024;
 
 struct SolverParams {

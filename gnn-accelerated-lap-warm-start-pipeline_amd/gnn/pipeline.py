@@ -88,7 +88,7 @@ class WarmStartPipeline:
 
     def seeded_batch(self, C: torch.Tensor, u: torch.Tensor, v: torch.Tensor, eps: float = 1e-12,
                      want_stats: bool = True):
-        """Batched lapjv_seeded: x, y (B,n) int64, ret (B,) int32, stats (B,16) int64."""
+        """Batched lapjv_seeded: x, y (B,n) int64, ret (B,) int32, stats (B,32) int64."""
         C = C.contiguous()
         B, n, _ = C.shape
         u = u.to(torch.float64).contiguous()
@@ -96,7 +96,7 @@ class WarmStartPipeline:
         x = torch.empty((B, n), dtype=torch.int64, device=C.device)
         y = torch.empty((B, n), dtype=torch.int64, device=C.device)
         ret = torch.empty((B,), dtype=torch.int32, device=C.device)
-        stats = torch.zeros((B, 16), dtype=torch.int64, device=C.device) if want_stats else None
+        stats = torch.zeros((B, 32), dtype=torch.int64, device=C.device) if want_stats else None
         ws, nbytes = self._workspace(B, n)
         stream = torch.cuda.current_stream(C.device).cuda_stream
         rc = self.lib.lapwarm_seeded_batched(
@@ -114,7 +114,7 @@ class WarmStartPipeline:
         x = torch.empty((B, n), dtype=torch.int32, device=C.device)
         y = torch.empty((B, n), dtype=torch.int32, device=C.device)
         ret = torch.empty((B,), dtype=torch.int32, device=C.device)
-        stats = torch.zeros((B, 16), dtype=torch.int64, device=C.device) if want_stats else None
+        stats = torch.zeros((B, 32), dtype=torch.int64, device=C.device) if want_stats else None
         ws, nbytes = self._workspace(B, n)
         stream = torch.cuda.current_stream(C.device).cuda_stream
         rc = self.lib.lapwarm_lapjv_batched(C.data_ptr(), B, n, x.data_ptr(), y.data_ptr(), ret.data_ptr(),

@@ -8,8 +8,11 @@ from __future__ import annotations
 import ctypes as ct
 from pathlib import Path
 
+import os
+
 _PKG_ROOT = Path(__file__).resolve().parent.parent
-LIB_PATH = _PKG_ROOT / "liblapwarm_hip.so"
+# LAPWARM_HIP_LIB selects another build of the same library (e.g. the -DLAPWARM_STAMPS diagnostic one)
+LIB_PATH = Path(os.environ.get("LAPWARM_HIP_LIB", _PKG_ROOT / "liblapwarm_hip.so"))
 
 c_dp = ct.POINTER(ct.c_double)
 c_fp = ct.POINTER(ct.c_float)

@@ -60,16 +60,17 @@ int lapwarm_reduce_costs(const double *C, int n, const double *u, const double *
  *     Every function returns 0 or <= -1000 (HIP error); per-instance codes go to `ret`.
  * ---------------------------------------------------------------------------------------- */
 
-#define LAPWARM_STATS_PER_INSTANCE 16
+#define LAPWARM_STATS_PER_INSTANCE 32
 /* stats[b][...]: 0 branch (1 ssp, 2 all matched, 3 fallback, 4 cold), 1 tight edges,
  * 2 free rows, 3 micro-ARR firings, 4 paths, 5 minima collections, 6 relax steps,
  * 7 relax elements (sum of n-hi), 8 path-init elements, 9 column-reduction elements,
- * 10 reduction-transfer rows, 11 ARR iterations, 12 internal error bits. */
+ * 10 reduction-transfer rows, 11 ARR iterations, 12 internal error bits, 13 kernel time and
+ * 14 greedy+micro-ARR time (10 ns ticks); 16..31 cycle stamps, only in -DLAPWARM_STAMPS builds. */
 
 size_t lapwarm_seeded_workspace_bytes(int batch, int n);
 
 /* Batched lapjv_seeded over C[batch][n][n]; u_seed, v_seed [batch][n]; x, y [batch][n] int64;
- * ret [batch] int; stats [batch][16] int64 or NULL.  `threads_hint` = workgroup size of the
+ * ret [batch] int; stats [batch][32] int64 or NULL.  `threads_hint` = workgroup size of the
  * per-instance kernel (0 = auto). */
 int lapwarm_seeded_batched(const double *C, int batch, int n, const double *u_seed,
                            const double *v_seed, double eps, long long *x, long long *y, int *ret,

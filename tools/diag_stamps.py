@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Cycle anatomy of the shortest-path loop from the -DLAPWARM_STAMPS build (diagnostic)."""
+import os, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+os.environ["LAPWARM_HIP_LIB"] = str(ROOT / "gnn-accelerated-lap-warm-start-pipeline_amd" / "liblapwarm_hip_stamps.so")
+sys.path[:0] = [str(ROOT), str(ROOT / "gnn-accelerated-lap-warm-start-pipeline_amd")]
+import numpy as np, torch
+from gnn import OneGNN, WarmStartPipeline
+from solvers.generators import mixed_batch
+B, n = 32, 2048
+hint = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+Cs, fams = mixed_batch(B, n, seed=1234)
+torch.manual_seed(0)
+pipe = WarmStartPipeline(OneGNN(21, hidden=192, layers=4).eval(), "cuda:0", threads_hint=hint)
+C = torch.from_numpy(Cs).cuda()
+u, v = pipe.predict_batch(C)
+for _ in range(2):
+    x, y, ret, st = pipe.seeded_batch(C, u, v)
+torch.cuda.synchronize()
+st = st.cpu().numpy()
+names = ["find", "relax:issue loads", "relax:wait+compute+publish", "relax:barrier", "relax:post", "n cnt0", "n cnt1", "n cnt>=2", "path init"]
+for f in ("uniform", "sparse", "clustered"):
+    idx = [b for b in range(B) if fams[b] == f]
+    s = st[idx].mean(0)
+    tot_ms = s[13] / 1e5
+    print(f"{f}: kernel {tot_ms:.1f} ms, paths {s[4]:.0f} finds {s[5]:.0f} steps {s[6]:.0f}")
+    cyc = s[16:25]
+    total_cyc = cyc[0] + cyc[1] + cyc[2] + cyc[3] + cyc[4] + cyc[8]
+    for k, nm in enumerate(names):
+        if nm.startswith("n "):
+            print(f"   {nm:28s} {cyc[k]:10.0f}")
+        else:
+            per = cyc[k] / (s[5] if k == 0 else (s[4] if k == 8 else s[6]))
+            print(f"   {nm:28s} {cyc[k]/1e6:8.2f} Mcycles  ({100*cyc[k]/total_cyc:5.1f}%)  {per:8.0f} cycles each")
+    fn = ["find:pre-B1", "find:B1 wait", "find:flags+atomics", "find:B2 wait", "find:replay(w0)", "find:B3 wait"]
+    for k, nm in enumerate(fn):
+        print(f"      {nm:24s} {s[16+9+k]/s[5]:8.0f} cycles per find")
+    print(f"      events per find          {s[16+15]/s[5]:8.1f}")
+    print(f"   stamped total {total_cyc/1e6:.1f} Mcycles -> {total_cyc/ (tot_ms*1e-3) / 1e9:.2f} GHz-equivalent")

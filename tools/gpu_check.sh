@@ -23,7 +23,7 @@ for s in "$@"; do
     bench)   step bench 600 python bench.py --steps 2 --warmup 1 ;;
     bench256) step bench256 300 python bench.py --steps 2 --warmup 1 --threads-hint 256 --cpu-sample 0 ;;
     bench1024) step bench1024 300 python bench.py --steps 2 --warmup 1 --threads-hint 1024 --cpu-sample 0 ;;
-    diag)    step diag 600 python tools/diag_k3.py 32 2048 0 512 ;;
+    diag)    step diag 600 python tools/diag_k3.py 32 2048 1024 512 256 128 ;;
     prof)    export TMPDIR=/tmp; step prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 ;;
     *) echo "unknown step $s" ;;
   esac
