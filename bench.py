@@ -38,6 +38,21 @@ def serial_elems(stats_row, n):
     return int(stats_row[8] + stats_row[7] + stats_row[9] + n * stats_row[10] + n * stats_row[11])
 
 
+def recorded_traffic(kernel_prefix="jv_instance_kernel"):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
+    cannot run inside the timed process; see profiles/*_pmc_traffic.txt).  None if absent."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json")):
+        try:
+            meta = json.loads(f.read_text())
+        except Exception:
+            continue
+        for k, d in meta.get("kernels", {}).items():
+            if k.startswith(kernel_prefix):
+                best = d.get("hbm_bytes_per_launch_corrected")
+    return best
+
+
 def cpu_baseline(C_host, sd, sample_idx):
     """Oracle pipeline (NumPy features + torch-CPU OneGNN + C restatement of lapjv_seeded) on a
     bounded sample, one thread (the reference's methodology pins 1 thread)."""
@@ -168,10 +183,12 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 6),
-                "traffic": None,
+                "traffic": recorded_traffic() if (B, n) == (32, 2048) else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(solver_avg_ms, 3),
-                "note": "latency-bound chain of dependent row scans; bytes = 8*E, E counted by the kernel",
+                "note": "latency-bound chain of dependent row scans; achieved = 8*E/launch time with E counted "
+                        "by the kernel; traffic = HBM bytes per launch from separate rocprofv3 --pmc passes "
+                        "(profiles/*_pmc_traffic.txt, 2*FETCH_SIZE+WRITE_SIZE)",
             },
         }
         if world == 1 and args.cpu_sample > 0:

@@ -25,6 +25,10 @@ for s in "$@"; do
     bench1024) step bench1024 300 python bench.py --steps 2 --warmup 1 --threads-hint 1024 --cpu-sample 0 ;;
     diag)    step diag 600 python tools/diag_k3.py 32 2048 1024 512 256 128 ;;
     prof)    export TMPDIR=/tmp; step prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 ;;
+    hostapi) step hostapi 600 python tools/diag_hostapi.py ;;
+    pmc)     export TMPDIR=/tmp
+             step pmc_fetch 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o r01 -- python3 bench.py --steps 1 --warmup 1 --cpu-sample 0
+             step pmc_write 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o r01 -- python3 bench.py --steps 1 --warmup 1 --cpu-sample 0 ;;
     *) echo "unknown step $s" ;;
   esac
 done

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Condense the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py into
+profiles/<tag>_pmc_traffic.{json,txt}.  gfx950 correction (MI355X_MICROARCH.md, HBM section):
+FETCH_SIZE under-reports coalesced streaming reads by exactly 2x -- confirmed here on kernels
+with a known byte count (colmin_partial: 16 B/lane, row_features: 8 B/lane, both read
+batch*n*n*8 bytes and report half of it); WRITE_SIZE is exact.  Counter unit: KiB."""
+import csv, collections, json, re, sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = {}
+for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    rows = list(csv.DictReader(open(ROOT / f"gpurun_out/pmc_{kind}/{tag}_counter_collection.csv")))
+    agg = collections.defaultdict(list)
+    for r in rows:
+        m = re.search(r"lapwarm::\(anonymous namespace\)::(\w+)(<[^>]*>)?", r["Kernel_Name"])
+        if m and r["Counter_Name"] == ctr:
+            agg[m.group(1) + (m.group(2) or "")].append(float(r["Counter_Value"]) * 1024.0)
+    for k, v in agg.items():
+        mx = max(v) if v else 0.0
+        nz = [x for x in v if x > 0.1 * mx] or [0.0]  # skip the early-exit re-launches
+        out.setdefault(k, {})[ctr] = {"launches": len(v), "mean_bytes_nonzero_launches": sum(nz) / len(nz)}
+for k, d in out.items():
+    f = d.get("FETCH_SIZE", {}).get("mean_bytes_nonzero_launches", 0.0)
+    w = d.get("WRITE_SIZE", {}).get("mean_bytes_nonzero_launches", 0.0)
+    d["hbm_bytes_per_launch_corrected"] = 2.0 * f + w
+meta = {"workload": "bench.py K3 (batch 32, n 2048, mixed families)", "correction": "2*FETCH_SIZE + WRITE_SIZE (KiB counters)",
+        "kernels": out}
+(ROOT / "profiles" / f"{tag}_pmc_traffic.json").write_text(json.dumps(meta, indent=1))
+lines = [f"{'kernel':44s} {'FETCH raw MiB':>14s} {'WRITE MiB':>10s} {'HBM corrected MiB':>18s}"]
+for k, d in sorted(out.items()):
+    lines.append(f"{k:44s} {d.get('FETCH_SIZE',{}).get('mean_bytes_nonzero_launches',0)/2**20:14.1f} "
+                 f"{d.get('WRITE_SIZE',{}).get('mean_bytes_nonzero_launches',0)/2**20:10.1f} {d['hbm_bytes_per_launch_corrected']/2**20:18.1f}")
+(ROOT / "profiles" / f"{tag}_pmc_traffic.txt").write_text("\n".join(lines) + "\n")
+print("\n".join(lines))
