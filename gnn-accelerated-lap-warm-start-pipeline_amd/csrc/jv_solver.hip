@@ -79,7 +79,8 @@ struct Solver {
     double *dist, *v;
     int *order, *pred, *y, *x, *fr;
     uint32_t *evt, *sbits, *used, *evb;
-    int *evlist;  // 64 entries: events of one minima collection, in position order
+    int *evl;     // n entries: events of one minima collection, in position order
+    int *tmpcol;  // n+1 entries: tie columns while they are re-packed
     Ctrl *ctrl;
     BlockCtx bc;
     // uniform counters (identical in every thread)
@@ -100,124 +101,142 @@ struct Solver {
     }
 
     // ------------------------------------------------------------------ event replay (wave 0)
-    // Minima collection, lapjv.cpp:153-171, given the event / strict bitmaps.
+    // Minima collection with ties, lapjv.cpp:153-171, from the event / strict bitmaps.
     //
-    // Fast path (at most 64 events, the usual case): the serial swap sequence touches only the
-    // event positions and the slots order[lo .. lo+m).  Wave 0 keeps those 64 slots as one value
-    // per lane ("window"), gathers the event columns in parallel -- order[e_i] cannot have been
-    // modified before its own turn, because every earlier target slot is < lo+i <= e_i -- and
-    // replays the swaps with readlane/writelane (no LDS round trip per event).  Larger event
-    // counts take the LDS loop below.
+    // Events in position order: e_0 < e_1 < ...  Let L be the index of the last STRICT event.
+    // Usual shape (measured: clustered family, ~3 strict events then ~150 ties with the global
+    // minimum): every event up to L is strict, everything after it is a tie.  Then
+    //   * events 0..L shift: position e_i receives the column that sat at e_(i-1) (at lo for
+    //     i = 0) and slot lo receives the column of e_L;
+    //   * the T ties after L fill slots lo+1 .. lo+T in order; slot lo+s held some column B
+    //     before: if lo+s is not itself a tie position, B ends at the first tie position OUTSIDE
+    //     the window reached by hopping s -> (t_s - lo) -> ...  (each hop is one serial swap that
+    //     moved B on); hops only go up, so every slot is resolved independently.
+    // Both parts are data-parallel over the lanes of wave 0.  A tie BEFORE the last strict event
+    // (rare) takes the serial loop.
     __device__ __forceinline__ void replay_find(int lo)
     {
         const int lane = bc.lane;
-        int hi = lo + 1;
-#ifdef LAPWARM_STAMPS
-        int n_events = 0;
-#endif
-        // ---- gather the events in position order
-        int total = 0;
-        for (int wbase = 0; wbase < W; wbase += kWave) {
-            const int idx = wbase + lane;
-            const uint32_t ew = (idx < W) ? evt[idx] : 0u;
-            total += wave_sum_i32(__popc(ew));
+        // ---- 1. ordered event list: evl[i] = position | strict << 31
+        const int wpl = (W + kWave - 1) / kWave;  // bitmap words per lane, contiguous per lane
+        int mine = 0;
+        for (int q = 0; q < wpl; ++q) {
+            const int idx = lane * wpl + q;
+            if (idx < W) mine += __popc(evt[idx]);
         }
-#ifdef LAPWARM_STAMPS
-        n_events = total;
-#endif
-        if (total <= kWave) {
-            int base_cnt = 0;
-            for (int wbase = 0; wbase < W; wbase += kWave) {
-                const int idx = wbase + lane;
-                uint32_t ew = 0, sw = 0;
-                if (idx < W) {
-                    ew = evt[idx];
-                    sw = sbits[idx];
-                    if (ew) {
-                        evt[idx] = 0;
-                        sbits[idx] = 0;
-                    }
-                }
-                const int mine = __popc(ew);
-                int incl = mine;
+        int incl = mine;
 #pragma unroll
-                for (int off = 1; off < kWave; off <<= 1) {
-                    const int o = __shfl_up(incl, off, kWave);
-                    if (lane >= off) incl += o;
+        for (int off = 1; off < kWave; off <<= 1) {
+            const int o = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += o;
+        }
+        const int E = __shfl(incl, kWave - 1, kWave);
+        int slot = incl - mine;
+        int last_strict_local = -1;
+        for (int q = 0; q < wpl; ++q) {
+            const int idx = lane * wpl + q;
+            if (idx < W) {
+                uint32_t ew = evt[idx];
+                const uint32_t sw = sbits[idx];
+                if (ew) {
+                    evt[idx] = 0;
+                    sbits[idx] = 0;
                 }
-                int slot = base_cnt + incl - mine;
                 while (ew) {
                     const int bit = __builtin_ctz(ew);
                     ew &= ew - 1;
-                    evlist[slot++] = ((idx << 5) + bit) | (int)(((sw >> bit) & 1u) << 31);
+                    const int st = (sw >> bit) & 1u;
+                    if (st) last_strict_local = slot;
+                    evl[slot++] = ((idx << 5) + bit) | (st << 31);
                 }
-                base_cnt += __shfl(incl, kWave - 1, kWave);
             }
-            // lane i owns event i
-            int kv = 0, cv = 0;
-            if (lane < total) {
-                kv = evlist[lane];
-                cv = order[kv & 0x7fffffff];
-            }
-            int win = (lo + lane < n) ? order[lo + lane] : 0;
-            int outv = 0;
-            int used_slots = 1;
-            for (int i = 0; i < total; ++i) {
-                const int ki = __builtin_amdgcn_readlane(kv, i);
-                const int c = __builtin_amdgcn_readlane(cv, i);
-                const int pos = ki & 0x7fffffff;
-                if (ki < 0) hi = lo;  // strict event
-                const int q = hi - lo;
-                const int a = __builtin_amdgcn_readlane(win, q);
-                win = (lane == q) ? c : win;
-                const int rel = pos - lo;
-                if (rel < kWave)
-                    win = (lane == rel) ? a : win;
-                else
-                    outv = (lane == i) ? a : outv;
+        }
+        int L = last_strict_local;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const int o = __shfl_xor(L, m, kWave);
+            L = (o > L) ? o : L;
+        }
+        // a tie before the last strict event?
+        bool early_tie = false;
+        for (int i = lane; i < L; i += kWave) early_tie |= (evl[i] >= 0);
+        int hi;
+        if (__ballot(early_tie) != 0ull || L + 1 > kWave) {
+            // ---- serial replay (exact for any pattern)
+            hi = lo + 1;
+            for (int i = 0; i < E; ++i) {
+                const int ev = evl[i];
+                const int k = ev & 0x7fffffff;
+                const int j = order[k];
+                if (ev < 0) hi = lo;
+                const int a = order[hi];
+                if (lane == 0) {
+                    order[k] = a;
+                    order[hi] = j;
+                }
+                fence_if_global();
                 ++hi;
-                if (q + 1 > used_slots) used_slots = q + 1;
             }
-            // write back: the window slots and the out-of-window event positions
-            if (total > 0) {
-                if (lo + lane < n) order[lo + lane] = win;
-                if (lane < total && (kv & 0x7fffffff) - lo >= kWave) order[kv & 0x7fffffff] = outv;
+        } else {
+            // ---- 2. strict prefix 0..L: shift
+            const int T = E - (L + 1);
+            for (int base_i = 0; base_i <= L; base_i += kWave) {
+                const int i = base_i + lane;
+                int newcol = 0, e = 0;
+                if (i <= L) {
+                    e = evl[i] & 0x7fffffff;
+                    newcol = order[(i == 0) ? lo : (evl[i - 1] & 0x7fffffff)];
+                }
+                const int lastcol = (L >= 0) ? order[evl[L] & 0x7fffffff] : 0;
+                // all reads of this chunk precede its writes (one wave, in-order LDS); chunks
+                // beyond the first read order[evl[i-1]] of the previous chunk's last event, which
+                // that chunk has already overwritten -- keep L+1 <= 64 on this path
+                if (i <= L) order[e] = newcol;
+                if (base_i == 0 && L >= 0 && lane == 0) order[lo] = lastcol;
             }
             fence_if_global();
-        } else {
-            for (int wbase = 0; wbase < W; wbase += kWave) {
-                const int idx = wbase + lane;
-                uint32_t ew = 0, sw = 0;
-                if (idx < W) {
-                    ew = evt[idx];
-                    sw = sbits[idx];
-                    if (ew) {
-                        evt[idx] = 0;
-                        sbits[idx] = 0;
-                    }
-                }
-                unsigned long long mask = __ballot(ew != 0);
-                while (mask) {
-                    const int l = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    uint32_t e = __shfl(ew, l, kWave);
-                    const uint32_t s = __shfl(sw, l, kWave);
-                    while (e) {
-                        const int bit = __builtin_ctz(e);
-                        e &= e - 1;
-                        const int k = ((wbase + l) << 5) + bit;
-                        const int j = order[k];
-                        if ((s >> bit) & 1u) hi = lo;
-                        const int a = order[hi];
-                        if (lane == 0) {
-                            order[k] = a;
-                            order[hi] = j;
+            // ---- 3. tie tail
+            const int tb = L + 1;  // evl[tb + s - 1] = position of tie number s (1-based)
+            for (int s0 = 1; s0 <= T; s0 += kWave) {  // save the tie columns
+                const int sidx = s0 + lane;
+                if (sidx <= T) tmpcol[sidx] = order[evl[tb + sidx - 1] & 0x7fffffff];
+            }
+            fence_if_global();
+            for (int s0 = 1; s0 <= T; s0 += kWave) {  // move the displaced columns out of the window
+                const int sidx = s0 + lane;
+                if (sidx <= T) {
+                    const int p0 = lo + sidx;
+                    // is p0 itself one of the tail ties?  t_s >= lo+s, so look at ties <= s
+                    int tpos = evl[tb + sidx - 1] & 0x7fffffff;
+                    bool is_tie;
+                    {
+                        // binary search p0 among the (sorted) tie positions t_1..t_sidx
+                        int lo_i = 1, hi_i = sidx;
+                        while (lo_i < hi_i) {
+                            const int mid = (lo_i + hi_i) >> 1;
+                            if ((evl[tb + mid - 1] & 0x7fffffff) < p0)
+                                lo_i = mid + 1;
+                            else
+                                hi_i = mid;
                         }
-                        fence_if_global();
-                        ++hi;
+                        is_tie = ((evl[tb + lo_i - 1] & 0x7fffffff) == p0);
+                    }
+                    if (!is_tie) {
+                        const int col = order[p0];
+                        int p = tpos;
+                        int guard = 0;
+                        while (p <= lo + T && guard++ < n) p = evl[tb + (p - lo) - 1] & 0x7fffffff;
+                        order[p] = col;  // a tie position outside the window: nobody reads it again
                     }
                 }
             }
+            fence_if_global();
+            for (int s0 = 1; s0 <= T; s0 += kWave) {  // pack the ties behind slot lo
+                const int sidx = s0 + lane;
+                if (sidx <= T) order[lo + sidx] = tmpcol[sidx];
+            }
+            fence_if_global();
+            hi = lo + 1 + T;
         }
         // last free column of the SCAN list wins (lapjv.cpp:250-255)
         int best = -1;
@@ -230,8 +249,8 @@ struct Solver {
             best = (o > best) ? o : best;
         }
         const int target = (best >= 0) ? order[best] : -1;
-        const double level = dist[order[lo]];
         const int head_j = order[lo];
+        const double level = dist[head_j];
         const int head_i = y[head_j];
         if (lane == 0) {
             ctrl->hi = hi;
@@ -1017,8 +1036,15 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
     cur += sizeof(uint32_t) * Wpad;
     s.evb = reinterpret_cast<uint32_t *>(cur);
     cur += sizeof(uint32_t) * Wpad;
-    s.evlist = reinterpret_cast<int *>(cur);
-    cur += sizeof(int) * kWave;
+    if constexpr (LDSL > 0) {
+        s.evl = reinterpret_cast<int *>(cur);
+        cur += sizeof(int) * n;
+        s.tmpcol = reinterpret_cast<int *>(cur);
+        cur += sizeof(int) * (n + 2);
+    } else {
+        s.evl = p.g_evl + (size_t)b * n;
+        s.tmpcol = p.g_tmpcol + (size_t)b * (n + 2);
+    }
     if constexpr (LDSL > 0) {
         s.dist = reinterpret_cast<double *>(cur);
         cur += sizeof(double) * n;
@@ -1195,8 +1221,8 @@ size_t solver_lds_bytes(int n, int ch, int level)
     const int W = (n + 31) >> 5;
     const int Wpad = (W + 1) & ~1;
     (void)ch;
-    size_t bytes = sizeof(BlockExchange) + sizeof(Ctrl) + sizeof(uint32_t) * (size_t)Wpad * 4 + sizeof(int) * kWave;
-    if (level >= 1) bytes += (size_t)n * (2 * sizeof(double) + 3 * sizeof(int));
+    size_t bytes = sizeof(BlockExchange) + sizeof(Ctrl) + sizeof(uint32_t) * (size_t)Wpad * 4;
+    if (level >= 1) bytes += (size_t)n * (2 * sizeof(double) + 5 * sizeof(int)) + 2 * sizeof(int);
     if (level >= 2) bytes += (size_t)n * 2 * sizeof(int);
     return bytes;
 }

@@ -40,7 +40,7 @@ struct SolverParams {
     long long *stats;          // [batch][kStatsPerInstance] or null
     // per-instance state in global memory, only used when the state does not fit LDS
     double *g_dist, *g_v;
-    int *g_order, *g_pred, *g_y, *g_x, *g_fr, *g_pos;
+    int *g_order, *g_pred, *g_y, *g_x, *g_fr, *g_evl, *g_tmpcol;
 };
 
 size_t solver_lds_bytes(int n, int ch, int level);

@@ -50,7 +50,7 @@ struct SeededWs {
     int *viol_cnt, *tight_cnt, *flags;
     uint32_t *tight_bits;
     double *g_dist, *g_v;
-    int *g_order, *g_pred, *g_y, *g_x, *g_fr, *g_pos;
+    int *g_order, *g_pred, *g_y, *g_x, *g_fr, *g_evl, *g_tmpcol;
     size_t bytes;
 };
 
@@ -75,10 +75,11 @@ SeededWs carve_seeded(void *ws, int batch, int n)
         s.g_y = c.take<int>(bn);
         s.g_x = c.take<int>(bn);
         s.g_fr = c.take<int>(bn);
-        s.g_pos = c.take<int>(bn);
+        s.g_evl = c.take<int>(bn);
+        s.g_tmpcol = c.take<int>(bn + 2 * (size_t)batch);
     } else {
         s.g_dist = s.g_v = nullptr;
-        s.g_order = s.g_pred = s.g_y = s.g_x = s.g_fr = s.g_pos = nullptr;
+        s.g_order = s.g_pred = s.g_y = s.g_x = s.g_fr = s.g_evl = s.g_tmpcol = nullptr;
     }
     s.bytes = c.off;
     return s;
@@ -247,7 +248,8 @@ int lapwarm_seeded_batched(const double *C, int batch, int n, const double *u_se
     sp.g_y = w.g_y;
     sp.g_x = w.g_x;
     sp.g_fr = w.g_fr;
-    sp.g_pos = w.g_pos;
+    sp.g_evl = w.g_evl;
+    sp.g_tmpcol = w.g_tmpcol;
     HIP_TRY(profile_begin(stream));
     HIP_TRY(launch_solver(sp, threads_hint, stream));
     HIP_TRY(profile_end(stream));
@@ -282,7 +284,8 @@ int lapwarm_lapjv_batched(const double *C, int batch, int n, int *x, int *y, int
     sp.g_y = w.g_y;
     sp.g_x = w.g_x;
     sp.g_fr = w.g_fr;
-    sp.g_pos = w.g_pos;
+    sp.g_evl = w.g_evl;
+    sp.g_tmpcol = w.g_tmpcol;
     HIP_TRY(profile_begin(stream));
     HIP_TRY(launch_solver(sp, threads_hint, stream));
     HIP_TRY(profile_end(stream));
