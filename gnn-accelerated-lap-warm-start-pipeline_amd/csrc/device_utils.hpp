@@ -22,6 +22,18 @@ constexpr int kFlagProjected = 4;       // the projection kernel changed (u,v): 
 // divergent branch that consumes it, which serialises the memory latencies of a thread's gathers.
 __device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
 
+// Values that are identical in every lane (read from a uniform LDS address, or the result of a
+// full butterfly) are moved to scalar registers so that the control state machine of the solver
+// runs on the scalar unit instead of being replicated on the vector ALUs of 16 waves.
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ double uni(double x)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffLL));
+    const int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 __device__ __forceinline__ double pos_inf() { return __longlong_as_double(0x7ff0000000000000LL); }
 
 __device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b : a; }

@@ -419,8 +419,8 @@ struct Solver {
                             pp = o4;
                         }
                     }
-                    totv = av;
-                    totp = ap;
+                    totv = uni(av);
+                    totp = uni(ap);
                     if (pair_less(pv, pp, runv, runp)) {
                         runv = pv;
                         runp = pp;
@@ -457,7 +457,7 @@ struct Solver {
                 int prevcol[CH];
 #pragma unroll
                 for (int r = 0; r < CH; ++r) prevcol[r] = (prevpos[r] >= 0) ? order[prevpos[r]] : 0;
-                const int min_col = order[totp];  // column of the global minimum (uniform)
+                const int min_col = uni(order[totp]);  // column of the global minimum (uniform)
                 if (tie) ctrl->tie_find = find_seq;
                 STAMP(tfd);
                 STAMP_ADD(11, tfd, tfc);
@@ -465,7 +465,7 @@ struct Solver {
                 STAMP(tfe);
                 STAMP_ADD(12, tfe, tfd);
                 finds++;
-                if (ctrl->tie_find != find_seq) {
+                if (uni(ctrl->tie_find) != find_seq) {
                     // ---- tie-free: apply the shift locally
 #pragma unroll
                     for (int r = 0; r < CH; ++r) {
@@ -481,7 +481,7 @@ struct Solver {
                     hi = lo + 1;
                     level = totv;
                     head_j = min_col;
-                    head_i = y[min_col];
+                    head_i = uni(y[min_col]);
                     target = (head_i < 0) ? head_j : -1;
                     STAMP(tff);
                     STAMP_ADD(13, tff, tfe);
@@ -495,11 +495,11 @@ struct Solver {
                     __syncthreads();
                     if (bc.wave == 0) replay_find(lo);
                     __syncthreads();
-                    hi = ctrl->hi;
-                    target = ctrl->target;
-                    level = ctrl->level;
-                    head_j = ctrl->head_j;
-                    head_i = ctrl->head_i;
+                    hi = uni(ctrl->hi);
+                    target = uni(ctrl->target);
+                    level = uni(ctrl->level);
+                    head_j = uni(ctrl->head_j);
+                    head_i = uni(ctrl->head_i);
                     STAMP(tfg);
                     STAMP_ADD(14, tfg, tfe);
                     STAMP_INC(15);
@@ -579,7 +579,7 @@ struct Solver {
             __syncthreads();
             STAMP(tr3);
             STAMP_ADD(3, tr3, tr2);
-            const int tot = ctrl->ev_total[par];
+            const int tot = uni(ctrl->ev_total[par]);
             const int cnt = tot - seen;
             if (par)
                 seen1 = tot;
@@ -592,12 +592,16 @@ struct Solver {
                 STAMP_INC(5);
                 ++lo;
                 if (lo != hi) {
-                    head_j = order[lo];
-                    head_i = y[head_j];
+                    head_j = uni(order[lo]);
+                    head_i = uni(y[head_j]);
                 }
             } else if (cnt == 1) {
                 STAMP_INC(6);
-                const EventSlot sl = ctrl->slot[par];
+                EventSlot sl = ctrl->slot[par];
+                sl.j = uni(sl.j);
+                sl.p = uni(sl.p);
+                sl.i = uni(sl.i);
+                sl.a = uni(sl.a);
                 if (sl.p >= b0 && sl.p < b0 + CH) {
                     // we own the event position: it now holds the column displaced from order[hi]
                     evb[sl.p >> 5] = 0;  // the only bit set in this step
@@ -625,19 +629,19 @@ struct Solver {
                     head_j = sl.j;
                     head_i = sl.i;
                 } else {
-                    head_j = order[lo];
-                    head_i = y[head_j];
+                    head_j = uni(order[lo]);
+                    head_i = uni(y[head_j]);
                 }
             } else {
                 STAMP_INC(7);
                 if (bc.wave == 0) replay_scan(hi);
                 __syncthreads();
-                hi = ctrl->hi;
-                target = ctrl->target;
+                hi = uni(ctrl->hi);
+                target = uni(ctrl->target);
                 if (target >= 0) break;
                 ++lo;
-                head_j = order[lo];
-                head_i = y[head_j];
+                head_j = uni(order[lo]);
+                head_i = uni(y[head_j]);
 #pragma unroll
                 for (int r = 0; r < CH; ++r) {
                     const int k = b0 + r;
@@ -671,7 +675,7 @@ struct Solver {
     __device__ __forceinline__ void augment_all(int n_free)
     {
         for (int f = 0; f < n_free && !err; ++f) {
-            const int start = fr[f];
+            const int start = uni(fr[f]);
             const int target = find_path(start);
             if (err) break;
             if (bc.tid == 0) {
