@@ -48,6 +48,7 @@ struct Ctrl {
     int hi;
     int target;
     int tie_find;     // sequence number of the last minima collection that saw a tie
+    int a_pub[2];     // column at order[hi], published each step by the owner of that position
     int ev_total[2];  // monotonic tie-event counters, one per step parity (readers diff them;
                       // a reader of step t can never see an increment of step t+1)
     int first_fire;
@@ -60,7 +61,16 @@ constexpr int kSentinelIdx = 0x7ffffffe;  // the LARGE sentinel of the ARR scan 
 constexpr int kEmptyIdx = 0x7fffffff;
 
 #ifdef LAPWARM_STAMPS
-#define STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+// s_memtime returns through the LGKM counter and out of order with LDS reads: the wait must be
+// part of the same asm statement, or the compiler's counted lgkmcnt waits pair up with the wrong
+// LDS read and the kernel computes on stale registers (cdna_hip_programming.md, in-kernel stamps).
+__device__ __forceinline__ unsigned long long stamp_now()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define STAMP(var) const unsigned long long var = stamp_now()
 #define STAMP_ADD(slot, t1, t0) stamps[slot] += (long long)((t1) - (t0))
 #define STAMP_INC(slot) stamps[slot] += 1
 #else
@@ -78,7 +88,10 @@ struct Solver {
     // state
     double *dist, *v;
     int *order, *pred, *y, *x, *fr;
-    uint32_t *evt, *sbits, *used, *evb;
+    uint32_t *evt, *sbits, *used;
+    uint32_t *evb;  // tie-event bitmap of a relax step, TWO copies selected by the step parity: the
+                    // post phase of step t clears bits while pass t+1 may already be setting its own
+    int Wpad;
     int *evl;     // n entries: events of one minima collection, in position order
     int *tmpcol;  // n+1 entries: tie columns while they are re-packed
     Ctrl *ctrl;
@@ -262,9 +275,10 @@ struct Solver {
     }
 
     // Several tie events in one relax step (lapjv.cpp:199-205): replay them in position order.
-    __device__ __forceinline__ void replay_scan(int hi)
+    __device__ __forceinline__ void replay_scan(int hi, int par)
     {
         const int lane = bc.lane;
+        uint32_t *evb = this->evb + (size_t)par * Wpad;
         int target = -1;
         for (int wbase = 0; wbase < W; wbase += kWave) {
             const int idx = wbase + lane;
@@ -314,7 +328,8 @@ struct Solver {
         // (1024-thread workgroups cap a thread at 128 VGPRs)
         constexpr bool CACHE_V = CH <= 4;
         double dk[CH], vr[CACHE_V ? CH : 1];
-        int jr[CH];
+        constexpr bool CACHE_Y = CH <= 2;
+        int jr[CH], yr[CACHE_Y ? CH : 1];  // yr: matched row of the owned column (y is constant during a path)
         {
             // every load is issued before the first use: indices are clamped instead of
             // branching, so the CH gathers of a thread are all in flight together
@@ -332,7 +347,10 @@ struct Solver {
             for (int r = 0; r < CH; ++r) {
                 const int k = b0 + r;
                 const double vk = v[jr[r]];
-                if constexpr (CACHE_V) vr[r] = vk;
+                if constexpr (CACHE_V) {
+                    vr[r] = vk;
+                    if constexpr (CACHE_Y) yr[r] = y[jr[r]];
+                }
                 const double val = c0[r] - vk;
                 dk[r] = (k < n) ? val : pos_inf();
                 if (k < n) {
@@ -350,6 +368,7 @@ struct Solver {
         STAMP_ADD(8, tp0, tpath);
         int seen0 = ctrl_seen0, seen1 = ctrl_seen1;
         int find_seq = ctrl_find_seq;
+        int app_pos = -1, app_j = 0, app_i = 0;  // last column appended by a single-event step
         double level = 0.0;
         int guard = 0;
         while (target < 0) {
@@ -474,7 +493,10 @@ struct Solver {
                             order[k] = prevcol[r];
                             jr[r] = prevcol[r];
                             dk[r] = prevval[r];
-                            if constexpr (CACHE_V) vr[r] = v[prevcol[r]];
+                            if constexpr (CACHE_V) {
+                                vr[r] = v[prevcol[r]];
+                                if constexpr (CACHE_Y) yr[r] = y[prevcol[r]];
+                            }
                         }
                     }
                     if (totp != lo && lo >= b0 && lo < b0 + CH) order[lo] = min_col;
@@ -511,7 +533,10 @@ struct Solver {
                         if (k >= hi && k < n) {
                             const int j = order[k];
                             jr[r] = j;
-                            if constexpr (CACHE_V) vr[r] = v[j];
+                            if constexpr (CACHE_V) {
+                                vr[r] = v[j];
+                                if constexpr (CACHE_Y) yr[r] = y[j];
+                            }
                             dk[r] = dist[j];
                         }
                     }
@@ -521,18 +546,58 @@ struct Solver {
             }
             // ---------------- relax the head of the SCAN list (lapjv.cpp:185-207)
             STAMP(tr0);
+            // a row index must be a matched row; anything else means corrupted state -- never
+            // turn it into a global address
+            if (head_i < 0 || head_i >= n || head_j < 0 || head_j >= n) {
+                err = 6;
+                break;
+            }
             const double *row = C + (size_t)head_i * n;
             double c[CH];
 #pragma unroll
-            for (int r = 0; r < CH; ++r) c[r] = row[jr[r]];  // unconditional: all gathers in flight
+            for (int r = 0; r < CH; ++r) {
+                // never form a global address from an out-of-range column (would be a logic bug:
+                // flag it instead of faulting)
+                int jc = jr[r];
+                if ((unsigned)jc >= (unsigned)n) {
+                    ctrl->err = 7;
+                    jc = 0;
+                }
+                c[r] = row[jc];  // unconditional: all gathers in flight
+            }
             double c_head = row[head_j];
+            const int par = step_id & 1;
+            // While the gathers are in flight: (a) the next queued SCAN column, if there is one,
+            // is already known -- fetch it and its row now; (b) the owner of position hi publishes
+            // the column sitting there (what a single tie event will displace).
+            const bool queued = (lo + 1 < hi);
+            int nq_j = 0, nq_i = 0;
+            const int fwd_pos = app_pos;  // only meaningful for the pass that directly follows
+            app_pos = -1;
+            if (queued) {
+                if (lo + 1 == fwd_pos) {
+                    // appended by the previous step's single-event path: its owner may still be
+                    // writing order[app_pos] (no barrier since), so take it from registers
+                    nq_j = app_j;
+                    nq_i = app_i;
+                } else {
+                    nq_j = order[lo + 1];
+                    nq_i = y[nq_j];
+                }
+            }
+
+            if (hi >= b0 && hi < b0 + CH && hi < n) {
+#pragma unroll
+                for (int r = 0; r < CH; ++r)
+                    if (b0 + r == hi) ctrl->a_pub[par] = jr[r];
+            }
+            const double v_head = v[head_j];
 #pragma unroll
             for (int r = 0; r < CH; ++r) pin(c[r]);
             pin(c_head);
             STAMP(tr1);
             STAMP_ADD(1, tr1, tr0);
-            const double h = (c_head - v[head_j]) - level;
-            const int par = step_id & 1;
+            const double h = (c_head - v_head) - level;
             int my_events = 0, ev_r = -1;
 #pragma unroll
             for (int r = 0; r < CH; ++r) {
@@ -551,7 +616,7 @@ struct Solver {
                         if (cand == level) {
                             if (ev_r < 0) ev_r = r;
                             ++my_events;
-                            atomicOr(&evb[k >> 5], 1u << (k & 31));
+                            atomicOr(&evb[par * Wpad + (k >> 5)], 1u << (k & 31));
                         }
                     }
                 } else {
@@ -560,26 +625,36 @@ struct Solver {
             }
             const int seen = par ? seen1 : seen0;
             if (my_events) {
-                const int old = atomicAdd(&ctrl->ev_total[par], my_events);
-                if (old == seen) {
-                    int ej = 0;
+                // no returning atomic and no LDS read on this path: if this turns out to be the
+                // only event of the step the slot is exactly right, otherwise nobody reads it
+                atomicAdd(&ctrl->ev_total[par], my_events);
+                EventSlot sl;
+                sl.j = 0;
+                sl.i = 0;
 #pragma unroll
-                    for (int r = 0; r < CH; ++r)
-                        if (r == ev_r) ej = jr[r];
-                    EventSlot sl;
-                    sl.j = ej;
-                    sl.p = b0 + ev_r;
-                    sl.i = y[ej];
-                    sl.a = order[hi];
-                    ctrl->slot[par] = sl;
+                for (int r = 0; r < CH; ++r) {
+                    if (r == ev_r) {
+                        sl.j = jr[r];
+                        if constexpr (CACHE_Y)
+                            sl.i = yr[r];
+                        else
+                            sl.i = y[jr[r]];
+                    }
                 }
+                sl.p = b0 + ev_r;
+                sl.a = 0;
+                ctrl->slot[par] = sl;
             }
             STAMP(tr2);
             STAMP_ADD(2, tr2, tr1);
             __syncthreads();
             STAMP(tr3);
             STAMP_ADD(3, tr3, tr2);
-            const int tot = uni(ctrl->ev_total[par]);
+            // one LDS round trip for everything the post phase can need
+            const int tot_raw = ctrl->ev_total[par];
+            EventSlot sl = ctrl->slot[par];
+            const int a_raw = ctrl->a_pub[par];
+            const int tot = uni(tot_raw);
             const int cnt = tot - seen;
             if (par)
                 seen1 = tot;
@@ -591,27 +666,35 @@ struct Solver {
             if (cnt == 0) {
                 STAMP_INC(5);
                 ++lo;
-                if (lo != hi) {
-                    head_j = uni(order[lo]);
-                    head_i = uni(y[head_j]);
+                if (queued) {
+                    head_j = uni(nq_j);
+                    head_i = uni(nq_i);
                 }
             } else if (cnt == 1) {
                 STAMP_INC(6);
-                EventSlot sl = ctrl->slot[par];
                 sl.j = uni(sl.j);
                 sl.p = uni(sl.p);
                 sl.i = uni(sl.i);
-                sl.a = uni(sl.a);
+                sl.a = uni(a_raw);
+                if ((unsigned)sl.j >= (unsigned)n || (unsigned)sl.a >= (unsigned)n || (unsigned)sl.p >= (unsigned)n ||
+                    sl.i >= n) {
+                    err = 8;
+                    break;
+                }
                 if (sl.p >= b0 && sl.p < b0 + CH) {
                     // we own the event position: it now holds the column displaced from order[hi]
-                    evb[sl.p >> 5] = 0;  // the only bit set in this step
+                    evb[par * Wpad + (sl.p >> 5)] = 0;  // the only bit set in this step's copy
                     if (sl.i >= 0) {
                         const double va = v[sl.a], da = dist[sl.a];
+                        const int ya = y[sl.a];
 #pragma unroll
                         for (int r = 0; r < CH; ++r) {
                             if (b0 + r == sl.p) {
                                 jr[r] = sl.a;
-                                if constexpr (CACHE_V) vr[r] = va;
+                                if constexpr (CACHE_V) {
+                                    vr[r] = va;
+                                    if constexpr (CACHE_Y) yr[r] = ya;
+                                }
                                 dk[r] = da;
                             }
                         }
@@ -623,32 +706,43 @@ struct Solver {
                     target = sl.j;
                     break;
                 }
+                app_pos = hi;
+                app_j = sl.j;
+                app_i = sl.i;
                 ++hi;
                 ++lo;
-                if (lo == hi - 1) {
+                if (queued) {
+                    head_j = uni(nq_j);
+                    head_i = uni(nq_i);
+                } else {
                     head_j = sl.j;
                     head_i = sl.i;
-                } else {
-                    head_j = uni(order[lo]);
-                    head_i = uni(y[head_j]);
                 }
             } else {
                 STAMP_INC(7);
-                if (bc.wave == 0) replay_scan(hi);
+                if (bc.wave == 0) replay_scan(hi, par);
                 __syncthreads();
                 hi = uni(ctrl->hi);
                 target = uni(ctrl->target);
                 if (target >= 0) break;
                 ++lo;
-                head_j = uni(order[lo]);
-                head_i = uni(y[head_j]);
+                if (queued) {
+                    head_j = uni(nq_j);
+                    head_i = uni(nq_i);
+                } else {
+                    head_j = uni(order[lo]);
+                    head_i = uni(y[head_j]);
+                }
 #pragma unroll
                 for (int r = 0; r < CH; ++r) {
                     const int k = b0 + r;
                     if (k >= hi && k < n) {
                         const int j = order[k];
                         jr[r] = j;
-                        if constexpr (CACHE_V) vr[r] = v[j];
+                        if constexpr (CACHE_V) {
+                            vr[r] = v[j];
+                            if constexpr (CACHE_Y) yr[r] = y[j];
+                        }
                         dk[r] = dist[j];
                     }
                 }
@@ -1039,7 +1133,8 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
     s.used = reinterpret_cast<uint32_t *>(cur);
     cur += sizeof(uint32_t) * Wpad;
     s.evb = reinterpret_cast<uint32_t *>(cur);
-    cur += sizeof(uint32_t) * Wpad;
+    cur += sizeof(uint32_t) * Wpad * 2;
+    s.Wpad = Wpad;
     if constexpr (LDSL > 0) {
         s.evl = reinterpret_cast<int *>(cur);
         cur += sizeof(int) * n;
@@ -1123,6 +1218,7 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
         s.sbits[w] = 0;
         s.used[w] = 0;
         s.evb[w] = 0;
+        s.evb[Wpad + w] = 0;
     }
     int tight_local = 0;
     for (int j = tid; j < n; j += blockDim.x) {
@@ -1225,7 +1321,7 @@ size_t solver_lds_bytes(int n, int ch, int level)
     const int W = (n + 31) >> 5;
     const int Wpad = (W + 1) & ~1;
     (void)ch;
-    size_t bytes = sizeof(BlockExchange) + sizeof(Ctrl) + sizeof(uint32_t) * (size_t)Wpad * 4;
+    size_t bytes = sizeof(BlockExchange) + sizeof(Ctrl) + sizeof(uint32_t) * (size_t)Wpad * 5;
     if (level >= 1) bytes += (size_t)n * (2 * sizeof(double) + 5 * sizeof(int)) + 2 * sizeof(int);
     if (level >= 2) bytes += (size_t)n * 2 * sizeof(int);
     return bytes;

@@ -229,6 +229,34 @@ def test_pipeline_mixed_families_end_to_end(torch_cuda):
             assert np.array_equal(xo, x[b]) and np.array_equal(yo, y[b]), fams[b]
 
 
+@pytest.mark.parametrize("n,hint", [(1024, 1024), (1024, 512), (1024, 256), (2048, 1024), (2048, 512)])
+def test_batched_solver_across_workgroup_geometries(torch_cuda, n, hint):
+    """Same inputs through different workgroup geometries (1, 2, 4 or 8 positions per thread:
+    different code paths and timing): assignments and control-flow counters must equal the
+    oracle's for every instance, GNN-quality seeds, all four K3 families."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    from oracle import jv
+    from solvers.generators import mixed_batch
+    B = 8
+    Cs, fams = mixed_batch(B, n, seed=4242 + n)
+    torch.manual_seed(1)
+    pipe = WarmStartPipeline(OneGNN(21, hidden=64, layers=2).eval(), "cuda:0", threads_hint=hint)
+    C = torch.from_numpy(Cs).cuda()
+    u, v = pipe.predict_batch(C)
+    for rep in range(2):  # twice: no state may leak between launches
+        x, y, ret, stats = pipe.seeded_batch(C, u, v)
+        torch.cuda.synchronize()
+        xs, ys, rets, st = x.cpu().numpy(), y.cpu().numpy(), ret.cpu().numpy(), stats.cpu().numpy()
+        un, vn = u.cpu().numpy().astype(np.float64), v.cpu().numpy()
+        for b in range(B):
+            r, xo, yo, so = jv.seeded_raw(Cs[b], un[b], vn[b])
+            assert r == rets[b] == 0, (fams[b], r, rets[b], st[b, 12])
+            assert np.array_equal(xo, xs[b]) and np.array_equal(yo, ys[b]), (fams[b], rep)
+            for q, name in ((4, "paths"), (5, "finds"), (6, "scan_steps"), (7, "scan_elems"), (11, "arr_iters")):
+                assert st[b, q] == so[name], (fams[b], name, st[b, q], so[name])
+
+
 # --------------------------------------------------------------------------- wrappers / errors
 def test_solver_wrappers_and_error_behaviour():
     import lap

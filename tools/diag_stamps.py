@@ -19,6 +19,7 @@ for _ in range(2):
     x, y, ret, st = pipe.seeded_batch(C, u, v)
 torch.cuda.synchronize()
 st = st.cpu().numpy()
+print('ret nonzero:', int((ret != 0).sum()), 'err slots:', st[:,12].tolist()[:8])
 names = ["find", "relax:issue loads", "relax:wait+compute+publish", "relax:barrier", "relax:post", "n cnt0", "n cnt1", "n cnt>=2", "path init"]
 for f in ("uniform", "sparse", "clustered"):
     idx = [b for b in range(B) if fams[b] == f]
