@@ -1272,6 +1272,10 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
             p.y32_out[(size_t)b * n + j] = s.y[j];
         }
         if (p.v_out) p.v_out[(size_t)b * n + j] = s.v[j];
+        if (p.u_out) {
+            const int xj = s.x[j];  // row j is matched to column xj
+            p.u_out[(size_t)b * n + j] = (xj >= 0) ? s.C[(size_t)j * n + xj] - s.v[xj] : 0.0;
+        }
     }
     if (tid == 0) {
         p.ret[b] = err ? (-100 - err) : 0;

@@ -36,6 +36,7 @@ struct SolverParams {
     long long *x_out, *y_out;  // [batch][n] int64 (seeded API) or null
     int *x32_out, *y32_out;    // [batch][n] int32 (lapjv API) or null
     double *v_out;             // [batch][n] final column duals or null
+    double *u_out;             // [batch][n] u_i = C[i][x_i] - v[x_i] or null
     int *ret;                  // [batch]
     long long *stats;          // [batch][kStatsPerInstance] or null
     // per-instance state in global memory, only used when the state does not fit LDS

@@ -256,9 +256,29 @@ int lapwarm_seeded_batched(const double *C, int batch, int n, const double *u_se
     return 0;
 }
 
+static int lapjv_batched_impl(const double *C, int batch, int n, int *x, int *y, double *u, double *v,
+                              int *ret, long long *stats, void *workspace, size_t workspace_bytes,
+                              int threads_hint, void *stream_);
+
 int lapwarm_lapjv_batched(const double *C, int batch, int n, int *x, int *y, int *ret,
                           long long *stats, void *workspace, size_t workspace_bytes,
                           int threads_hint, void *stream_)
+{
+    return lapjv_batched_impl(C, batch, n, x, y, nullptr, nullptr, ret, stats, workspace, workspace_bytes,
+                              threads_hint, stream_);
+}
+
+int lapwarm_lapjv_duals_batched(const double *C, int batch, int n, int *x, int *y, double *u, double *v,
+                                int *ret, long long *stats, void *workspace, size_t workspace_bytes,
+                                int threads_hint, void *stream_)
+{
+    return lapjv_batched_impl(C, batch, n, x, y, u, v, ret, stats, workspace, workspace_bytes, threads_hint,
+                              stream_);
+}
+
+static int lapjv_batched_impl(const double *C, int batch, int n, int *x, int *y, double *u, double *v,
+                              int *ret, long long *stats, void *workspace, size_t workspace_bytes,
+                              int threads_hint, void *stream_)
 {
     if (int rc = check_dims(batch, n)) return rc;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
@@ -275,6 +295,8 @@ int lapwarm_lapjv_batched(const double *C, int batch, int n, int *x, int *y, int
     sp.mode = kModeCold;
     sp.x32_out = x;
     sp.y32_out = y;
+    sp.v_out = v;
+    sp.u_out = u;
     sp.ret = ret;
     sp.stats = stats;
     sp.g_dist = w.g_dist;

@@ -124,6 +124,25 @@ class WarmStartPipeline:
             raise RuntimeError(f"lapwarm_lapjv_batched failed (code {rc}): {_hip.last_error()}")
         return x, y, ret, stats
 
+    def optimal_duals_batch(self, C: torch.Tensor):
+        """Cold JV + the optimal duals it ends with: x (B,n) int32, u, v (B,n) fp64, ret.
+        u_i = C[i, x_i] - v[x_i]; (u, v) is feasible and tight on the optimal assignment."""
+        C = C.contiguous()
+        B, n, _ = C.shape
+        x = torch.empty((B, n), dtype=torch.int32, device=C.device)
+        y = torch.empty((B, n), dtype=torch.int32, device=C.device)
+        u = torch.empty((B, n), dtype=torch.float64, device=C.device)
+        v = torch.empty((B, n), dtype=torch.float64, device=C.device)
+        ret = torch.empty((B,), dtype=torch.int32, device=C.device)
+        ws, nbytes = self._workspace(B, n)
+        stream = torch.cuda.current_stream(C.device).cuda_stream
+        rc = self.lib.lapwarm_lapjv_duals_batched(C.data_ptr(), B, n, x.data_ptr(), y.data_ptr(), u.data_ptr(),
+                                                  v.data_ptr(), ret.data_ptr(), None, ws.data_ptr(), nbytes,
+                                                  self.threads_hint, ct.c_void_p(stream))
+        if _hip.check(rc, "optimal_duals_batch") != 0:
+            raise RuntimeError(f"lapwarm_lapjv_duals_batched failed (code {rc}): {_hip.last_error()}")
+        return x, u, v, ret
+
     @torch.inference_mode()
     def solve_batch(self, C: torch.Tensor, eps: float = 1e-12, want_stats: bool = True) -> dict:
         """The whole hot path for a resident batch."""

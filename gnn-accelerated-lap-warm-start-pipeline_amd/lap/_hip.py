@@ -33,6 +33,8 @@ SIGNATURES = {
                                           c_vp, c_vp, c_vp, ct.c_size_t, ct.c_int, c_vp]),
     "lapwarm_lapjv_batched": (ct.c_int, [c_vp, ct.c_int, ct.c_int, c_vp, c_vp, c_vp, c_vp, c_vp,
                                          ct.c_size_t, ct.c_int, c_vp]),
+    "lapwarm_lapjv_duals_batched": (ct.c_int, [c_vp, ct.c_int, ct.c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                               ct.c_size_t, ct.c_int, c_vp]),
     "lapwarm_sweep_workspace_bytes": (ct.c_size_t, [ct.c_int, ct.c_int]),
     "lapwarm_colmin_batched": (ct.c_int, [c_vp, ct.c_int, ct.c_int, c_vp, c_vp, c_vp, ct.c_size_t, c_vp]),
     "lapwarm_row_features_batched": (ct.c_int, [c_vp, ct.c_int, ct.c_int, c_vp, c_vp, c_vp, c_vp,

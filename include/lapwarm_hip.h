@@ -82,6 +82,14 @@ int lapwarm_lapjv_batched(const double *C, int batch, int n, int *x, int *y, int
                           long long *stats, void *workspace, size_t workspace_bytes,
                           int threads_hint, void *stream);
 
+/* As lapwarm_lapjv_batched, and also returns the optimal dual pair of each instance:
+ * v [batch][n] = the solver's final column duals, u [batch][n] with u_i = C[i][x_i] - v[x_i]
+ * (complementary slackness on the matched edges).  This is how the K2 configuration gets its
+ * "oracle u" without the reference's O(n^3) Bellman-Ford (solvers/dual_computation.py:34-52). */
+int lapwarm_lapjv_duals_batched(const double *C, int batch, int n, int *x, int *y, double *u, double *v,
+                                int *ret, long long *stats, void *workspace, size_t workspace_bytes,
+                                int threads_hint, void *stream);
+
 size_t lapwarm_sweep_workspace_bytes(int batch, int n);
 
 /* out[b][j] = min_i (C[b][i][j] - u[b][i]); u may be NULL. */

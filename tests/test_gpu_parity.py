@@ -181,6 +181,38 @@ def test_batched_k2_counters_match_oracle(torch_cuda):
     assert seen == {1, 3}
 
 
+def test_k2_config_oracle_duals(torch_cuda):
+    """BASELINE configs[1] (K2): batch=64, n=512, uniform RandomState(42+i); u = optimal duals
+    derived from the cold JV, v = fp64 min-trick; HIP column minima + row features + seeded JV.
+    Every instance bit-exact against the oracle, duals feasible and tight on the optimum."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    from gnn.features import min_trick_device, row_features_device
+    from oracle import features_np, jv
+    B, n = 64, 512
+    Cs = np.stack([np.random.RandomState(42 + i).uniform(0, 1, (n, n)) for i in range(B)])
+    pipe = WarmStartPipeline(OneGNN(21), "cuda:0")
+    C = torch.from_numpy(Cs).cuda()
+    xc, u, v_opt, ret = pipe.optimal_duals_batch(C)
+    v = min_trick_device(C, u)
+    feat, top16 = row_features_device(C)
+    x, y, ret2, stats = pipe.seeded_batch(C, u, v)
+    torch.cuda.synchronize()
+    assert int(ret.abs().sum()) == 0 and int(ret2.abs().sum()) == 0
+    un, vn, von = u.cpu().numpy(), v.cpu().numpy(), v_opt.cpu().numpy()
+    xs, ys, xcn = x.cpu().numpy(), y.cpu().numpy(), xc.cpu().numpy()
+    fn = feat.cpu().numpy()
+    for b in range(B):
+        red = Cs[b] - un[b][:, None] - von[b][None, :]
+        assert red.min() > -1e-9 and np.abs(red[np.arange(n), xcn[b]]).max() < 1e-9  # optimal dual pair
+        assert np.array_equal(vn[b], features_np.min_trick(Cs[b], un[b]))
+        r, xo, yo, _ = jv.seeded_raw(Cs[b], un[b], vn[b])
+        assert r == 0 and np.array_equal(xo, xs[b]) and np.array_equal(yo, ys[b]), b
+        assert abs(Cs[b][np.arange(n), xs[b]].sum() - Cs[b][np.arange(n), xcn[b]].sum()) < 1e-9
+        if b < 4:
+            np.testing.assert_allclose(fn[b], features_np.compute_row_features(Cs[b]), rtol=3e-6, atol=1e-9)
+
+
 @pytest.mark.parametrize("n", [2048, 4096, 5000])
 def test_full_size_single_instances(n):
     """BASELINE sizes through the drop-in API: LDS-resident state (2048, 4096) and the

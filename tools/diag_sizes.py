@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Correctness + timing probe of the pipeline at the larger BASELINE sizes (diagnostic)."""
+import sys, time
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(ROOT), str(ROOT / "gnn-accelerated-lap-warm-start-pipeline_amd")]
+import numpy as np, torch
+from gnn import OneGNN, WarmStartPipeline
+from oracle import jv
+
+torch.manual_seed(0)
+model = OneGNN(21, hidden=192, layers=4).eval()
+for n, B, check in [(4096, 8, 2), (8192, 2, 1), (16384, 1, 1)]:
+    if len(sys.argv) > 1 and str(n) not in sys.argv[1:]:
+        continue
+    Cs = np.stack([np.random.RandomState(42 + i).uniform(0, 1, (n, n)) for i in range(B)])
+    pipe = WarmStartPipeline(model, "cuda:0")
+    C = torch.from_numpy(Cs).cuda()
+    torch.cuda.synchronize()
+    for rep in range(2):
+        t0 = time.perf_counter()
+        out = pipe.solve_batch(C)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    st = out["stats"].cpu().numpy()
+    ret = out["ret"].cpu().numpy()
+    print(f"n={n} B={B}: {dt*1e3:.1f} ms/batch  ret={ret.tolist()} branch={st[:,0].tolist()} paths={st[:,4].tolist()} "
+          f"steps={st[:,6].tolist()} kernel_ms={[round(v/1e5,1) for v in st[:,13]]} err={st[:,12].tolist()}", flush=True)
+    u = out["u"].cpu().numpy().astype(np.float64); v = out["v"].cpu().numpy(); x = out["x"].cpu().numpy()
+    for b in range(check):
+        t0 = time.perf_counter()
+        r, xo, yo, so = jv.seeded_raw(Cs[b], u[b], v[b])
+        print(f"   oracle b={b}: {time.perf_counter()-t0:.1f} s  exact={bool(r == ret[b] and np.array_equal(xo, x[b]))} "
+              f"steps oracle={so['scan_steps']} gpu={st[b,6]}", flush=True)
