@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--threads-hint", type=int, default=0)
     ap.add_argument("--families", type=str, default="uniform,sparse,metric,clustered")
     ap.add_argument("--cpu-sample", type=int, default=8, help="instances timed on the host (0 = skip)")
+    ap.add_argument("--backend", type=str, default="nccl",
+                    help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse the "
+                         "multi-rank flow on a single GPU)")
     ap.add_argument("--config", type=str, default="K3", choices=["K2", "K3", "K4"],
                     help="K3 (default) is the configuration the metric is quoted on; K2 / K4 are the other "
                          "single-GPU-sized BASELINE configs (K4 = one GPU's 32-instance slice of batch 256)")
@@ -100,12 +103,19 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X (no CPU fallback for the HIP path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and local_rank >= ndev:
+        raise SystemExit("one GPU per rank is required with the nccl (RCCL) backend")
+    local_dev = local_rank % max(1, ndev)  # gloo rehearsal: ranks may share a GPU
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from gnn import OneGNN, WarmStartPipeline
     from lap import _hip
@@ -142,7 +152,9 @@ def main():
         else:
             out = pipe.solve_batch(C)
         if distributed:
-            out["x_all"] = gather_assignments(out["x"], dst=0)  # the one exchange step (RCCL)
+            # the one exchange step: assignments to rank 0 (RCCL; gloo needs host tensors)
+            xs = out["x"] if args.backend == "nccl" else out["x"].cpu()
+            out["x_all"] = gather_assignments(xs, dst=0)
         return out
 
     def sync():
@@ -165,7 +177,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -200,7 +212,8 @@ def main():
                     "costs resident in HBM" % (args.hidden, args.layers)),
                 "global_batch": B * world,
                 "n": n,
-                "parallelism": "batch-sharded x%d, one RCCL gather of assignments" % world,
+                "parallelism": "batch-sharded x%d, one %s gather of assignments" % (
+                    world, "RCCL" if args.backend == "nccl" else args.backend),
                 "solver_threads_hint": args.threads_hint,
                 "branches": branches,
                 "ret_nonzero": int((ret != 0).sum()),

@@ -79,9 +79,11 @@ __device__ __forceinline__ unsigned long long stamp_now()
 #define STAMP_INC(slot)
 #endif
 
-template <int CH, int LDSL>
+template <int CH, int LDSL, int TB>
 struct Solver {
     static constexpr bool LDS_STATE = LDSL > 0;
+    static constexpr int kCacheLimit = (TB <= 256) ? 16 : 4;   // positions per thread whose duals fit in registers
+    static constexpr int kCacheLimitY = (TB <= 256) ? 16 : 2;
     // problem
     const double *C;
     int n, W;
@@ -326,9 +328,9 @@ struct Solver {
         STAMP(tpath);
         // the duals of the owned columns are cached in registers while the budget allows
         // (1024-thread workgroups cap a thread at 128 VGPRs)
-        constexpr bool CACHE_V = CH <= 4;
+        constexpr bool CACHE_V = CH <= kCacheLimit;
         double dk[CH], vr[CACHE_V ? CH : 1];
-        constexpr bool CACHE_Y = CH <= 2;
+        constexpr bool CACHE_Y = CH <= kCacheLimitY;
         int jr[CH], yr[CACHE_Y ? CH : 1];  // yr: matched row of the owned column (y is constant during a path)
         {
             // every load is issued before the first use: indices are clamped instead of
@@ -1111,8 +1113,10 @@ struct Solver {
     }
 };
 
-template <int CH, int LDSL>
-__global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
+// TB = compile-time bound on the workgroup size: 1024-thread workgroups cap a thread at 128 VGPRs,
+// the 256-thread variant (one wave per SIMD) gets the whole register file.
+template <int CH, int LDSL, int TB>
+__global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int b = blockIdx.x;
@@ -1120,7 +1124,7 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
     const int W = (n + 31) >> 5;
     const int Wpad = (W + 1) & ~1;
 
-    Solver<CH, LDSL> s;
+    Solver<CH, LDSL, TB> s;
     unsigned char *cur = smem;
     BlockExchange *ex = reinterpret_cast<BlockExchange *>(cur);
     cur += sizeof(BlockExchange);
@@ -1306,10 +1310,10 @@ __global__ void __launch_bounds__(1024) jv_instance_kernel(SolverParams p)
     }
 }
 
-template <int CH, int LDSL>
+template <int CH, int LDSL, int TB>
 hipError_t launch_one(const SolverParams &p, int threads, size_t lds_bytes, hipStream_t stream)
 {
-    auto kern = jv_instance_kernel<CH, LDSL>;
+    auto kern = jv_instance_kernel<CH, LDSL, TB>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -1370,11 +1374,16 @@ hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t st
     const int level = solver_lds_level(p.n, ch);
     if (level < 2 && !p.g_dist) return hipErrorInvalidValue;
     const size_t lds = solver_lds_bytes(p.n, ch, level);
-#define LAPWARM_CASE(CHV)                                                         \
-    case CHV:                                                                     \
-        if (level == 2) return launch_one<CHV, 2>(p, threads, lds, stream);       \
-        if (level == 1) return launch_one<CHV, 1>(p, threads, lds, stream);       \
-        return launch_one<CHV, 0>(p, threads, lds, stream);
+#define LAPWARM_CASE(CHV)                                                               \
+    case CHV:                                                                           \
+        if (threads <= 256) {                                                           \
+            if (level == 2) return launch_one<CHV, 2, 256>(p, threads, lds, stream);    \
+            if (level == 1) return launch_one<CHV, 1, 256>(p, threads, lds, stream);    \
+            return launch_one<CHV, 0, 256>(p, threads, lds, stream);                    \
+        }                                                                               \
+        if (level == 2) return launch_one<CHV, 2, 1024>(p, threads, lds, stream);       \
+        if (level == 1) return launch_one<CHV, 1, 1024>(p, threads, lds, stream);       \
+        return launch_one<CHV, 0, 1024>(p, threads, lds, stream);
     switch (ch) {
         LAPWARM_CASE(1)
         LAPWARM_CASE(2)

@@ -23,12 +23,14 @@ for s in "$@"; do
     bench)   step bench 600 python bench.py --steps 2 --warmup 1 ;;
     bench256) step bench256 300 python bench.py --steps 2 --warmup 1 --threads-hint 256 --cpu-sample 0 ;;
     bench1024) step bench1024 300 python bench.py --steps 2 --warmup 1 --threads-hint 1024 --cpu-sample 0 ;;
-    diag)    step diag 600 python tools/diag_k3.py 32 2048 1024 512 256 128 ;;
+    diag)    step diag 600 python tools/diag_k3.py 32 2048 1024 256 ;;
     prof)    export TMPDIR=/tmp; step prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r01 -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 ;;
     hostapi) step hostapi 600 python tools/diag_hostapi.py ;;
     pmc)     export TMPDIR=/tmp
              step pmc_fetch 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o r01 -- python3 bench.py --steps 1 --warmup 1 --cpu-sample 0
              step pmc_write 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o r01 -- python3 bench.py --steps 1 --warmup 1 --cpu-sample 0 ;;
+    pmc_sq)  export TMPDIR=/tmp
+             step pmc_sq 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc_sq -o r01 -- python3 bench.py --steps 1 --warmup 1 --cpu-sample 0 ;;
     *) echo "unknown step $s" ;;
   esac
 done
