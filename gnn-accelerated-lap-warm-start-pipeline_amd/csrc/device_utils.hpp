@@ -43,29 +43,71 @@ __device__ __forceinline__ bool pair_less(double a, int ia, double b, int ib)
     return (a < b) || (a == b && ia < ib);
 }
 
+// ---- DPP data movement (gfx9 encodings): row_shr:n moves lane i-n -> i inside a row of 16 lanes,
+// row_bcast:15 / :31 broadcast the last lane of a row / of the lower half to the following rows.
+// Lanes without a source keep `old` (bound_ctrl = false), which callers set to the identity.
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_move(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double old, double src)
+{
+    const long long o = __double_as_longlong(old), x = __double_as_longlong(src);
+    const int lo = dpp_move<CTRL, ROW_MASK>((int)(o & 0xffffffffLL), (int)(x & 0xffffffffLL));
+    const int hi = dpp_move<CTRL, ROW_MASK>((int)(o >> 32), (int)(x >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int l)
+{
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Wave64 reduction skeleton: after the six steps lane 63 holds the reduction of all lanes.
+#define LAPWARM_DPP_REDUCE(STEP)      \
+    STEP(kDppRowShr1, 0xf)            \
+    STEP(kDppRowShr2, 0xf)            \
+    STEP(kDppRowShr4, 0xf)            \
+    STEP(kDppRowShr8, 0xf)            \
+    STEP(kDppRowBcast15, 0xa)         \
+    STEP(kDppRowBcast31, 0xc)
+
 // ---- wave-level reductions (all 64 lanes must be active) --------------------------------
 __device__ __forceinline__ double wave_min(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = dmin(v, __shfl_xor(v, m, kWave));
-    return v;
+#define LAPWARM_STEP(C, M) v = dmin(v, dpp_move<C, M>(pos_inf(), v));
+    LAPWARM_DPP_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+    return readlane_f64(v, kWave - 1);
 }
 
 __device__ __forceinline__ int wave_min_i32(int v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const int o = __shfl_xor(v, m, kWave);
-        v = (o < v) ? o : v;
+#define LAPWARM_STEP(C, M)                                  \
+    {                                                       \
+        const int o = dpp_move<C, M>(0x7fffffff, v);        \
+        v = (o < v) ? o : v;                                \
     }
-    return v;
+    LAPWARM_DPP_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+    return __builtin_amdgcn_readlane(v, kWave - 1);
 }
 
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-    return v;
+#define LAPWARM_STEP(C, M) v += dpp_move<C, M>(0, v);
+    LAPWARM_DPP_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+    return __builtin_amdgcn_readlane(v, kWave - 1);
 }
 
 __device__ __forceinline__ double wave_sum_f64(double v)
@@ -77,25 +119,31 @@ __device__ __forceinline__ double wave_sum_f64(double v)
 
 __device__ __forceinline__ double wave_max(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double o = __shfl_xor(v, m, kWave);
-        v = (o > v) ? o : v;
+#define LAPWARM_STEP(C, M)                                  \
+    {                                                       \
+        const double o = dpp_move<C, M>(-pos_inf(), v);     \
+        v = (o > v) ? o : v;                                \
     }
-    return v;
+    LAPWARM_DPP_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+    return readlane_f64(v, kWave - 1);
 }
 
 __device__ __forceinline__ void wave_min_pair(double &v, int &i)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const double ov = __shfl_xor(v, m, kWave);
-        const int oi = __shfl_xor(i, m, kWave);
-        if (pair_less(ov, oi, v, i)) {
-            v = ov;
-            i = oi;
-        }
+#define LAPWARM_STEP(C, M)                                          \
+    {                                                               \
+        const double ov = dpp_move<C, M>(pos_inf(), v);             \
+        const int oi = dpp_move<C, M>(0x7fffffff, i);               \
+        if (pair_less(ov, oi, v, i)) {                              \
+            v = ov;                                                 \
+            i = oi;                                                 \
+        }                                                           \
     }
+    LAPWARM_DPP_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+    v = readlane_f64(v, kWave - 1);
+    i = __builtin_amdgcn_readlane(i, kWave - 1);
 }
 
 // Two lexicographically smallest (value, index) pairs; "empty" = (+inf, INT_MAX).
@@ -150,16 +198,25 @@ __device__ __forceinline__ Top2 top2_merge(Top2 p, Top2 q)
 
 __device__ __forceinline__ Top2 wave_top2(Top2 t)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        Top2 o;
-        o.a1 = __shfl_xor(t.a1, m, kWave);
-        o.i1 = __shfl_xor(t.i1, m, kWave);
-        o.a2 = __shfl_xor(t.a2, m, kWave);
-        o.i2 = __shfl_xor(t.i2, m, kWave);
-        t = top2_merge(t, o);
+    // the element sets merged at every step are disjoint (prefix of a row / of the wave), so the
+    // merge of the two runner-up lists is exact
+#define LAPWARM_STEP(C, M)                                          \
+    {                                                               \
+        Top2 o;                                                     \
+        o.a1 = dpp_move<C, M>(pos_inf(), t.a1);                     \
+        o.i1 = dpp_move<C, M>(0x7fffffff, t.i1);                    \
+        o.a2 = dpp_move<C, M>(pos_inf(), t.a2);                     \
+        o.i2 = dpp_move<C, M>(0x7fffffff, t.i2);                    \
+        t = top2_merge(t, o);                                       \
     }
-    return t;
+    LAPWARM_DPP_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+    Top2 r;
+    r.a1 = readlane_f64(t.a1, kWave - 1);
+    r.i1 = __builtin_amdgcn_readlane(t.i1, kWave - 1);
+    r.a2 = readlane_f64(t.a2, kWave - 1);
+    r.i2 = __builtin_amdgcn_readlane(t.i2, kWave - 1);
+    return r;
 }
 
 // Exclusive prefix-min over the lanes of a wave (lane 0 gets +inf); *total = wave min.
@@ -176,23 +233,37 @@ __device__ __forceinline__ double wave_excl_prefix_min(double x, int lane, doubl
     return (lane == 0) ? pos_inf() : prev;
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void scan_step_min_pair(double &v, int &i)
+{
+    const double ov = dpp_move<CTRL, ROW_MASK>(pos_inf(), v);
+    const int oi = dpp_move<CTRL, ROW_MASK>(0x7fffffff, i);
+    if (pair_less(ov, oi, v, i)) {
+        v = ov;
+        i = oi;
+    }
+}
+
 // Exclusive prefix of the lexicographic (value, index) minimum over the lanes of a wave; lane 0
-// gets (+inf, INT_MAX).  (*tv, *ti) = the wave's total.
+// gets (+inf, INT_MAX).  (*tv, *ti) = the wave's total.  Six DPP steps (register-to-register,
+// no LDS crossbar round trips) + one shift.
 __device__ __forceinline__ void wave_excl_prefix_min_pair(double &v, int &idx, int lane, double *tv, int *ti)
 {
     double iv = v;
     int ii = idx;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const double ov = __shfl_up(iv, off, kWave);
-        const int oi = __shfl_up(ii, off, kWave);
-        if (lane >= off && pair_less(ov, oi, iv, ii)) {
-            iv = ov;
-            ii = oi;
-        }
+    scan_step_min_pair<kDppRowShr1, 0xf>(iv, ii);
+    scan_step_min_pair<kDppRowShr2, 0xf>(iv, ii);
+    scan_step_min_pair<kDppRowShr4, 0xf>(iv, ii);
+    scan_step_min_pair<kDppRowShr8, 0xf>(iv, ii);
+    scan_step_min_pair<kDppRowBcast15, 0xa>(iv, ii);
+    scan_step_min_pair<kDppRowBcast31, 0xc>(iv, ii);
+    {
+        const long long b = __double_as_longlong(iv);
+        const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), kWave - 1);
+        const int hi = __builtin_amdgcn_readlane((int)(b >> 32), kWave - 1);
+        *tv = __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+        *ti = __builtin_amdgcn_readlane(ii, kWave - 1);
     }
-    *tv = __shfl(iv, kWave - 1, kWave);
-    *ti = __shfl(ii, kWave - 1, kWave);
     const double pv = __shfl_up(iv, 1, kWave);
     const int pi = __shfl_up(ii, 1, kWave);
     v = (lane == 0) ? pos_inf() : pv;
