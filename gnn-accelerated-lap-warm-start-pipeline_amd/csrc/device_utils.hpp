@@ -270,15 +270,105 @@ __device__ __forceinline__ void wave_excl_prefix_min_pair(double &v, int &idx, i
     idx = (lane == 0) ? 0x7fffffff : pi;
 }
 
+// 16-lane row reduction (every row of the wave holds the same 16 values): lane 15 of each row ends
+// with the result; read it from lane 15.
+#define LAPWARM_DPP_ROW_REDUCE(STEP) \
+    STEP(kDppRowShr1, 0xf)           \
+    STEP(kDppRowShr2, 0xf)           \
+    STEP(kDppRowShr4, 0xf)           \
+    STEP(kDppRowShr8, 0xf)
+
 // ---- workgroup-level exchange through LDS ------------------------------------------------
 // Two alternating slot sets: call k writes set (k&1), one barrier, then reads it.  A thread
 // can only reach the write of call k+2 after the barrier of call k+1, which every reader of
 // call k has passed, so one barrier per call is enough.
 struct BlockExchange {
-    double d[2][kMaxWaves * 2];
+    double d[2][kMaxWaves * 4];
     double bcast[2];
-    int i[2][kMaxWaves * 2];
+    int i[2][kMaxWaves * 4];
 };
+
+// Two smallest (value, index) candidates of an ARR row scan with what the serial code reads next
+// as payload: v[j1], y[j1], y[j2].  Lanes (and waves) own ascending column ranges, so "lowest
+// lane / wave holding the minimum value" IS the lexicographic (value, index) tie-break; the
+// reduction therefore needs only value minima (DPP) + a ballot, not tuple merges.
+struct Arr2 {
+    double a1, vj1, a2;
+    int i1, y1, i2, y2;
+};
+
+__device__ __forceinline__ Arr2 arr2_empty()
+{
+    Arr2 t;
+    t.a1 = t.a2 = pos_inf();
+    t.vj1 = 0.0;
+    t.i1 = t.i2 = 0x7fffffff;
+    t.y1 = t.y2 = -1;
+    return t;
+}
+
+__device__ __forceinline__ void arr2_push(Arr2 &t, double a, int i, double vj, int yj)
+{
+    const bool first = pair_less(a, i, t.a1, t.i1);
+    const bool second = pair_less(a, i, t.a2, t.i2);
+    t.a2 = first ? t.a1 : (second ? a : t.a2);
+    t.i2 = first ? t.i1 : (second ? i : t.i2);
+    t.y2 = first ? t.y1 : (second ? yj : t.y2);
+    t.a1 = first ? a : t.a1;
+    t.i1 = first ? i : t.i1;
+    t.vj1 = first ? vj : t.vj1;
+    t.y1 = first ? yj : t.y1;
+}
+
+// Reduce over `width` consecutive lanes holding candidates in ascending index order (width = 64:
+// whole wave via the six-step DPP reduction; width = 16: one row).  Result is wave-uniform.
+template <int WIDTH>
+__device__ __forceinline__ Arr2 arr2_reduce_lanes(const Arr2 &t)
+{
+    constexpr int last = WIDTH - 1;
+    const unsigned long long lanes = (WIDTH == 64) ? ~0ull : 0xffffull;
+    double m1 = t.a1;
+    if constexpr (WIDTH == 64) {
+#define LAPWARM_STEP(C, M) m1 = dmin(m1, dpp_move<C, M>(pos_inf(), m1));
+        LAPWARM_DPP_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+    } else {
+#define LAPWARM_STEP(C, M) m1 = dmin(m1, dpp_move<C, M>(pos_inf(), m1));
+        LAPWARM_DPP_ROW_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+    }
+    m1 = readlane_f64(m1, last);
+    const unsigned long long k1 = __ballot(t.a1 == m1) & lanes;
+    const int l1 = k1 ? __builtin_ctzll(k1) : 0;  // all +inf / NaN: any lane, values are empty
+    Arr2 r;
+    r.a1 = readlane_f64(t.a1, l1);
+    r.vj1 = readlane_f64(t.vj1, l1);
+    r.i1 = __builtin_amdgcn_readlane(t.i1, l1);
+    r.y1 = __builtin_amdgcn_readlane(t.y1, l1);
+    const int lane = threadIdx.x & (kWave - 1);
+    const bool win = (lane & last) == l1 && (WIDTH == 64 || lane < 16 || true);
+    const double c2 = ((lane & last) == l1) ? t.a2 : t.a1;
+    const int c2i = ((lane & last) == l1) ? t.i2 : t.i1;
+    const int c2y = ((lane & last) == l1) ? t.y2 : t.y1;
+    (void)win;
+    double m2 = c2;
+    if constexpr (WIDTH == 64) {
+#define LAPWARM_STEP(C, M) m2 = dmin(m2, dpp_move<C, M>(pos_inf(), m2));
+        LAPWARM_DPP_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+    } else {
+#define LAPWARM_STEP(C, M) m2 = dmin(m2, dpp_move<C, M>(pos_inf(), m2));
+        LAPWARM_DPP_ROW_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+    }
+    m2 = readlane_f64(m2, last);
+    const unsigned long long k2 = __ballot(c2 == m2) & lanes;
+    const int l2 = k2 ? __builtin_ctzll(k2) : 0;
+    r.a2 = readlane_f64(c2, l2);
+    r.i2 = __builtin_amdgcn_readlane(c2i, l2);
+    r.y2 = __builtin_amdgcn_readlane(c2y, l2);
+    return r;
+}
 
 struct BlockCtx {
     int tid, lane, wave, nwaves;
@@ -306,9 +396,10 @@ struct BlockCtx {
         __syncthreads();
         const int w = lane & (kMaxWaves - 1);
         double r = (w < nwaves) ? ex->d[p][w] : pos_inf();
-#pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) r = dmin(r, __shfl_xor(r, m, kWave));
-        return r;
+#define LAPWARM_STEP(C, M) r = dmin(r, dpp_move<C, M>(pos_inf(), r));
+        LAPWARM_DPP_ROW_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+        return readlane_f64(r, 15);
     }
 
     // exclusive prefix-min over waves of the per-wave totals (after the caller's own barrier)
@@ -316,9 +407,10 @@ struct BlockCtx {
     {
         const int w = lane & (kMaxWaves - 1);
         double r = (w < wave) ? slots[w] : pos_inf();
-#pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) r = dmin(r, __shfl_xor(r, m, kWave));
-        return r;
+#define LAPWARM_STEP(C, M) r = dmin(r, dpp_move<C, M>(pos_inf(), r));
+        LAPWARM_DPP_ROW_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+        return readlane_f64(r, 15);
     }
 
     __device__ __forceinline__ double max_f64(double v)
@@ -358,12 +450,14 @@ struct BlockCtx {
         __syncthreads();
         const int w = lane & (kMaxWaves - 1);
         int r = (w < nwaves) ? ex->i[p][w] : 0x7fffffff;
-#pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) {
-            const int o = __shfl_xor(r, m, kWave);
-            r = (o < r) ? o : r;
-        }
-        return r;
+#define LAPWARM_STEP(C, M)                                  \
+    {                                                       \
+        const int o = dpp_move<C, M>(0x7fffffff, r);        \
+        r = (o < r) ? o : r;                                \
+    }
+        LAPWARM_DPP_ROW_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+        return __builtin_amdgcn_readlane(r, 15);
     }
 
     __device__ __forceinline__ int sum_i32(int v)
@@ -375,9 +469,10 @@ struct BlockCtx {
         __syncthreads();
         const int w = lane & (kMaxWaves - 1);
         int r = (w < nwaves) ? ex->i[p][w] : 0;
-#pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) r += __shfl_xor(r, m, kWave);
-        return r;
+#define LAPWARM_STEP(C, M) r += dpp_move<C, M>(0, r);
+        LAPWARM_DPP_ROW_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+        return __builtin_amdgcn_readlane(r, 15);
     }
 
     __device__ __forceinline__ void min_pair(double &v, int &idx)
@@ -402,6 +497,38 @@ struct BlockCtx {
         }
         v = r;
         idx = ri;
+    }
+
+    // Workgroup-wide Arr2 reduction; *c0 (owned by thread 0) is broadcast alongside.  One barrier.
+    __device__ __forceinline__ Arr2 arr2(const Arr2 &t, double *c0)
+    {
+        const Arr2 w = arr2_reduce_lanes<64>(t);
+        const int p = parity;
+        parity ^= 1;
+        if (lane == 0) {
+            ex->d[p][4 * wave + 0] = w.a1;
+            ex->d[p][4 * wave + 1] = w.vj1;
+            ex->d[p][4 * wave + 2] = w.a2;
+            ex->i[p][4 * wave + 0] = w.i1;
+            ex->i[p][4 * wave + 1] = w.y1;
+            ex->i[p][4 * wave + 2] = w.i2;
+            ex->i[p][4 * wave + 3] = w.y2;
+        }
+        if (tid == 0) ex->bcast[p] = *c0;
+        __syncthreads();
+        const int q = lane & (kMaxWaves - 1);
+        Arr2 s = arr2_empty();
+        if (q < nwaves) {
+            s.a1 = ex->d[p][4 * q + 0];
+            s.vj1 = ex->d[p][4 * q + 1];
+            s.a2 = ex->d[p][4 * q + 2];
+            s.i1 = ex->i[p][4 * q + 0];
+            s.y1 = ex->i[p][4 * q + 1];
+            s.i2 = ex->i[p][4 * q + 2];
+            s.y2 = ex->i[p][4 * q + 3];
+        }
+        *c0 = ex->bcast[p];
+        return arr2_reduce_lanes<16>(s);
     }
 
     // top2() that also broadcasts one double owned by thread 0
@@ -434,16 +561,23 @@ struct BlockCtx {
             r.i1 = ex->i[p][2 * w];
             r.i2 = ex->i[p][2 * w + 1];
         }
-#pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) {
-            Top2 o;
-            o.a1 = __shfl_xor(r.a1, m, kWave);
-            o.i1 = __shfl_xor(r.i1, m, kWave);
-            o.a2 = __shfl_xor(r.a2, m, kWave);
-            o.i2 = __shfl_xor(r.i2, m, kWave);
-            r = top2_merge(r, o);
-        }
-        return r;
+#define LAPWARM_STEP(C, M)                                          \
+    {                                                               \
+        Top2 o;                                                     \
+        o.a1 = dpp_move<C, M>(pos_inf(), r.a1);                     \
+        o.i1 = dpp_move<C, M>(0x7fffffff, r.i1);                    \
+        o.a2 = dpp_move<C, M>(pos_inf(), r.a2);                     \
+        o.i2 = dpp_move<C, M>(0x7fffffff, r.i2);                    \
+        r = top2_merge(r, o);                                       \
+    }
+        LAPWARM_DPP_ROW_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+        Top2 out;
+        out.a1 = readlane_f64(r.a1, 15);
+        out.i1 = __builtin_amdgcn_readlane(r.i1, 15);
+        out.a2 = readlane_f64(r.a2, 15);
+        out.i2 = __builtin_amdgcn_readlane(r.i2, 15);
+        return out;
     }
 };
 
