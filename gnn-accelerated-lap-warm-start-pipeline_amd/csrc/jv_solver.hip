@@ -1024,11 +1024,12 @@ struct Solver {
     }
 
     // lapjv.cpp:323-346
-    __device__ __forceinline__ int cold_solve()
+    // Column reduction + the two ARR sweeps; returns the rows still free (the caller runs the
+    // shortest-path phase, which is shared with the seeded branch -- one call site, one copy).
+    __device__ __forceinline__ int cold_prepare()
     {
         int nf = cold_column_reduction();
         for (int sweep = 0; nf > 0 && sweep < 2 && !err; ++sweep) nf = cold_arr_sweep(nf);
-        if (nf > 0 && !err) augment_all(nf);
         return nf;
     }
 
@@ -1246,33 +1247,35 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
     long long tight_total = 0;
     long long free_after_greedy = 0;
     int nf = 0;
+    bool cold = (p.mode != kModeSeeded);
     if (p.mode == kModeSeeded) {
         const int tt = s.bc.sum_i32(tight_local);  // includes the barrier that publishes the init
         tight_total = tt;
-        const bool fallback = (double)tt < 1.2 * n;  // lapjv_seeded.cpp:116
-        if (fallback) {
-            branch = kBranchFallback;
-            nf = s.cold_solve();
-        } else {
-            if (s.bc.wave == 0)
-                s.greedy_wave0(p.tight_bits + (size_t)b * n * W, p.tight_cnt + (size_t)b * n);
-            __syncthreads();
-            nf = s.ctrl->nfree;
-            free_after_greedy = nf;
-            if (nf == 0) {
-                branch = kBranchAllMatched;
-            } else {
-                branch = kBranchSsp;
-                s.micro_arr(nf, p.u_tight + (size_t)b * n, p.tight_eps);
-                t_serial = __builtin_amdgcn_s_memrealtime();
-                if (!s.err) s.augment_all(nf);
-            }
-        }
+        cold = (double)tt < 1.2 * n;  // quality gate, lapjv_seeded.cpp:116
+        if (cold) branch = kBranchFallback;
     } else {
         __syncthreads();
-        nf = s.cold_solve();
-        free_after_greedy = nf;
     }
+    bool run_paths = false;
+    if (cold) {
+        nf = s.cold_prepare();
+        free_after_greedy = nf;
+        run_paths = nf > 0;
+    } else {
+        if (s.bc.wave == 0) s.greedy_wave0(p.tight_bits + (size_t)b * n * W, p.tight_cnt + (size_t)b * n);
+        __syncthreads();
+        nf = s.ctrl->nfree;
+        free_after_greedy = nf;
+        if (nf == 0) {
+            branch = kBranchAllMatched;
+        } else {
+            branch = kBranchSsp;
+            s.micro_arr(nf, p.u_tight + (size_t)b * n, p.tight_eps);
+            t_serial = __builtin_amdgcn_s_memrealtime();
+            run_paths = true;
+        }
+    }
+    if (run_paths && !s.err) s.augment_all(nf);
     __syncthreads();
     const int err = s.err | s.ctrl->err;
     for (int j = tid; j < n; j += blockDim.x) {
