@@ -600,29 +600,44 @@ struct Solver {
             STAMP(tr1);
             STAMP_ADD(1, tr1, tr0);
             const double h = (c_head - v_head) - level;
+            // branch-free core (select, not jump, per element); the LDS bookkeeping of improved
+            // columns and the rare tie events sit behind one thread-level test each
             int my_events = 0, ev_r = -1;
+            unsigned imp_bits = 0, ev_mask = 0;
 #pragma unroll
             for (int r = 0; r < CH; ++r) {
                 const int k = b0 + r;
-                if (k >= hi && k < n) {
-                    double vj;
-                    if constexpr (CACHE_V)
-                        vj = vr[r];
-                    else
-                        vj = v[jr[r]];
-                    const double cand = (c[r] - vj) - h;
-                    if (cand < dk[r]) {
-                        dk[r] = cand;
-                        dist[jr[r]] = cand;
+                const bool act = (k >= hi) & (k < n);
+                double vj;
+                if constexpr (CACHE_V)
+                    vj = vr[r];
+                else
+                    vj = v[jr[r]];
+                const double cand = (c[r] - vj) - h;
+                const bool imp = act & (cand < dk[r]);
+                const bool ev = imp & (cand == level);
+                dk[r] = imp ? cand : (act ? dk[r] : pos_inf());
+                imp_bits |= imp ? (1u << r) : 0u;
+                ev_mask |= ev ? (1u << r) : 0u;
+            }
+            if (imp_bits) {
+#pragma unroll
+                for (int r = 0; r < CH; ++r) {
+                    if ((imp_bits >> r) & 1u) {
+                        dist[jr[r]] = dk[r];
                         pred[jr[r]] = head_i;
-                        if (cand == level) {
-                            if (ev_r < 0) ev_r = r;
+                    }
+                }
+                if (ev_mask) {
+#pragma unroll
+                    for (int r = CH - 1; r >= 0; --r) {
+                        if ((ev_mask >> r) & 1u) {
+                            ev_r = r;
                             ++my_events;
+                            const int k = b0 + r;
                             atomicOr(&evb[par * Wpad + (k >> 5)], 1u << (k & 31));
                         }
                     }
-                } else {
-                    dk[r] = pos_inf();
                 }
             }
             const int seen = par ? seen1 : seen0;
