@@ -83,7 +83,9 @@ def main():
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--threads-hint", type=int, default=0)
     ap.add_argument("--families", type=str, default="uniform,sparse,metric,clustered")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="instances timed on the host (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=32,
+                    help="instances of the same batch timed through the CPU oracle pipeline on rank 0 at N=1 "
+                         "(0 = skip); 32 x n=2048 is ~10 s of single-core work")
     ap.add_argument("--backend", type=str, default="nccl",
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse the "
                          "multi-rank flow on a single GPU)")
@@ -95,7 +97,7 @@ def main():
         args.batch, args.n, args.families = 64, 512, "uniform"
     elif args.config == "K4":  # batch=256 n=4096 over 8 GPUs -> 32 per GPU
         args.batch, args.n, args.families = 32, 4096, "uniform"
-        args.cpu_sample = min(args.cpu_sample, 4)
+        args.cpu_sample = min(args.cpu_sample, 8)  # ~0.7 s per n=4096 instance on one core
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
