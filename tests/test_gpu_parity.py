@@ -234,6 +234,30 @@ def test_full_size_single_instances(n):
         assert abs(C[np.arange(n), xc].sum() - cost) < 1e-9  # seeded and cold agree on the optimum
 
 
+@pytest.mark.parametrize("n", [8192, 16384])
+def test_large_n_pipeline_exact(torch_cuda, n):
+    """K5-sized instance (n=16384) and n=8192: solver state no longer fits LDS (global-workspace
+    variant), features run with the 128-KiB LDS row.  Whole pipeline, one instance, bit-exact
+    assignment and identical relax-step count against the oracle fed the GPU's own (u, v)."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    from oracle import jv
+    C = np.random.RandomState(42).uniform(0, 1, (n, n))
+    torch.manual_seed(0)
+    pipe = WarmStartPipeline(OneGNN(21, hidden=64, layers=2).eval(), "cuda:0")
+    out = pipe.solve_batch(torch.from_numpy(C).cuda().unsqueeze(0))
+    torch.cuda.synchronize()
+    assert int(out["ret"][0]) == 0
+    x = out["x"][0].cpu().numpy()
+    assert np.array_equal(np.sort(x), np.arange(n))
+    u = out["u"][0].cpu().numpy().astype(np.float64)
+    v = out["v"][0].cpu().numpy()
+    r, xo, yo, so = jv.seeded_raw(C, u, v)
+    assert r == 0 and np.array_equal(xo, x) and np.array_equal(yo, out["y"][0].cpu().numpy())
+    st = out["stats"][0].cpu().numpy()
+    assert st[6] == so["scan_steps"] and st[4] == so["paths"] and st[7] == so["scan_elems"]
+
+
 def test_pipeline_mixed_families_end_to_end(torch_cuda):
     """K3-shaped (reduced batch): features + OneGNN + min-trick + seeded solve, all families.
     u/v within 1e-5 of the CPU forward; assignments bit-exact given the GPU's own (u, v)."""
