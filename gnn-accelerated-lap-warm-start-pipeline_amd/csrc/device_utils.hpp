@@ -251,6 +251,26 @@ __device__ __forceinline__ void wave_excl_prefix_min_pair(double &v, int &idx, i
 {
     double iv = v;
     int ii = idx;
+#ifdef LAPWARM_NO_DPP_SCAN
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const double ov = __shfl_up(iv, off, kWave);
+        const int oi = __shfl_up(ii, off, kWave);
+        if (lane >= off && pair_less(ov, oi, iv, ii)) {
+            iv = ov;
+            ii = oi;
+        }
+    }
+    *tv = __shfl(iv, kWave - 1, kWave);
+    *ti = __shfl(ii, kWave - 1, kWave);
+    {
+        const double pv0 = __shfl_up(iv, 1, kWave);
+        const int pi0 = __shfl_up(ii, 1, kWave);
+        v = (lane == 0) ? pos_inf() : pv0;
+        idx = (lane == 0) ? 0x7fffffff : pi0;
+        return;
+    }
+#endif
     scan_step_min_pair<kDppRowShr1, 0xf>(iv, ii);
     scan_step_min_pair<kDppRowShr2, 0xf>(iv, ii);
     scan_step_min_pair<kDppRowShr4, 0xf>(iv, ii);

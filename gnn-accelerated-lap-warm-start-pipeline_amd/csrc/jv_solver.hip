@@ -70,11 +70,24 @@ __device__ __forceinline__ unsigned long long stamp_now()
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     return t;
 }
-#define STAMP(var) const unsigned long long var = stamp_now()
+#ifndef LAPWARM_STAMP_GROUPS
+#define LAPWARM_STAMP_GROUPS 7  // bit 0: minima collection, bit 1: relax step, bit 2: path
+#endif
+#define STAMP_G(g, var) const unsigned long long var = ((LAPWARM_STAMP_GROUPS) & (g)) ? stamp_now() : 0ull
+#ifndef LAPWARM_FIND_MASK
+#define LAPWARM_FIND_MASK 0x1ff
+#endif
+#define STAMP_FI(bit, var) const unsigned long long var = (((LAPWARM_STAMP_GROUPS) & 1) && ((LAPWARM_FIND_MASK) >> (bit) & 1)) ? stamp_now() : 0ull
+#define STAMP(var) STAMP_G(1, var)
+#define STAMPR(var) STAMP_G(2, var)
+#define STAMPP(var) STAMP_G(4, var)
 #define STAMP_ADD(slot, t1, t0) stamps[slot] += (long long)((t1) - (t0))
 #define STAMP_INC(slot) stamps[slot] += 1
 #else
 #define STAMP(var)
+#define STAMPR(var)
+#define STAMPP(var)
+#define STAMP_FI(bit, var)
 #define STAMP_ADD(slot, t1, t0)
 #define STAMP_INC(slot)
 #endif
@@ -325,7 +338,7 @@ struct Solver {
     {
         const int b0 = base();
         const int wordi = b0 >> 5, shift = b0 & 31;
-        STAMP(tpath);
+        STAMPP(tpath);
         // the duals of the owned columns are cached in registers while the budget allows
         // (1024-thread workgroups cap a thread at 128 VGPRs)
         constexpr bool CACHE_V = CH <= kCacheLimit;
@@ -366,7 +379,7 @@ struct Solver {
         init_elems += n;
         int lo = 0, hi = 0, ready = 0, target = -1;
         int head_j = 0, head_i = 0;
-        STAMP(tp0);
+        STAMPP(tp0);
         STAMP_ADD(8, tp0, tpath);
         int seen0 = ctrl_seen0, seen1 = ctrl_seen1;
         int find_seq = ctrl_find_seq;
@@ -387,7 +400,7 @@ struct Solver {
                 // event position receives the column of the previous record holder and slot lo
                 // receives the final minimum -- applied here by the event owners themselves, no
                 // ordered replay.  Any tie anywhere sends the whole collection to the exact replay.
-                STAMP(tf0);
+                STAMP_FI(0, tf0);
                 ready = lo;
                 ++find_seq;
                 double tv = pos_inf();
@@ -410,10 +423,10 @@ struct Solver {
                     bc.ex->d[xp][bc.wave] = wtv;
                     bc.ex->i[xp][bc.wave] = wtp;
                 }
-                STAMP(tfa);
+                STAMP_FI(1, tfa);
                 STAMP_ADD(9, tfa, tf0);
                 __syncthreads();
-                STAMP(tfb);
+                STAMP_FI(2, tfb);
                 STAMP_ADD(10, tfb, tfa);
                 double totv;
                 int totp;
@@ -447,7 +460,7 @@ struct Solver {
                         runp = pp;
                     }
                 }
-                STAMP(tfc);
+                STAMP_FI(3, tfc);
                 // classify the owned positions; remember what each strict event receives
                 uint32_t eb = 0, sb = 0;
                 bool tie = false;
@@ -480,10 +493,10 @@ struct Solver {
                 for (int r = 0; r < CH; ++r) prevcol[r] = (prevpos[r] >= 0) ? order[prevpos[r]] : 0;
                 const int min_col = uni(order[totp]);  // column of the global minimum (uniform)
                 if (tie) ctrl->tie_find = find_seq;
-                STAMP(tfd);
+                STAMP_FI(4, tfd);
                 STAMP_ADD(11, tfd, tfc);
                 __syncthreads();
-                STAMP(tfe);
+                STAMP_FI(5, tfe);
                 STAMP_ADD(12, tfe, tfd);
                 finds++;
                 if (uni(ctrl->tie_find) != find_seq) {
@@ -507,7 +520,7 @@ struct Solver {
                     head_j = min_col;
                     head_i = uni(y[min_col]);
                     target = (head_i < 0) ? head_j : -1;
-                    STAMP(tff);
+                    STAMP_FI(6, tff);
                     STAMP_ADD(13, tff, tfe);
                     if (target >= 0) break;
                 } else {
@@ -524,7 +537,7 @@ struct Solver {
                     level = uni(ctrl->level);
                     head_j = uni(ctrl->head_j);
                     head_i = uni(ctrl->head_i);
-                    STAMP(tfg);
+                    STAMP_FI(7, tfg);
                     STAMP_ADD(14, tfg, tfe);
                     STAMP_INC(15);
                     if (target >= 0) break;
@@ -543,11 +556,11 @@ struct Solver {
                         }
                     }
                 }
-                STAMP(tf1);
+                STAMP_FI(8, tf1);
                 STAMP_ADD(0, tf1, tf0);
             }
             // ---------------- relax the head of the SCAN list (lapjv.cpp:185-207)
-            STAMP(tr0);
+            STAMPR(tr0);
             // a row index must be a matched row; anything else means corrupted state -- never
             // turn it into a global address
             if (head_i < 0 || head_i >= n || head_j < 0 || head_j >= n) {
@@ -597,7 +610,7 @@ struct Solver {
 #pragma unroll
             for (int r = 0; r < CH; ++r) pin(c[r]);
             pin(c_head);
-            STAMP(tr1);
+            STAMPR(tr1);
             STAMP_ADD(1, tr1, tr0);
             const double h = (c_head - v_head) - level;
             // branch-free core (select, not jump, per element); the LDS bookkeeping of improved
@@ -662,10 +675,10 @@ struct Solver {
                 sl.a = 0;
                 ctrl->slot[par] = sl;
             }
-            STAMP(tr2);
+            STAMPR(tr2);
             STAMP_ADD(2, tr2, tr1);
             __syncthreads();
-            STAMP(tr3);
+            STAMPR(tr3);
             STAMP_ADD(3, tr3, tr2);
             // one LDS round trip for everything the post phase can need
             const int tot_raw = ctrl->ev_total[par];
@@ -764,7 +777,7 @@ struct Solver {
                     }
                 }
             }
-            STAMP(tr4);
+            STAMPR(tr4);
             STAMP_ADD(4, tr4, tr3);
         }
         ctrl_seen0 = seen0;

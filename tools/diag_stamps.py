@@ -3,7 +3,7 @@
 import os, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
-os.environ["LAPWARM_HIP_LIB"] = str(ROOT / "gnn-accelerated-lap-warm-start-pipeline_amd" / "liblapwarm_hip_stamps.so")
+os.environ["LAPWARM_HIP_LIB"] = os.environ.get("LAPWARM_STAMP_LIB", str(ROOT / "gnn-accelerated-lap-warm-start-pipeline_amd" / "liblapwarm_hip_stamps.so"))
 sys.path[:0] = [str(ROOT), str(ROOT / "gnn-accelerated-lap-warm-start-pipeline_amd")]
 import numpy as np, torch
 from gnn import OneGNN, WarmStartPipeline
