@@ -324,6 +324,13 @@ int lapwarm_colmin_batched(const double *C, int batch, int n, const double *u, d
     return 0;
 }
 
+int lapwarm_rowmin_batched(const double *C, int batch, int n, const double *v, double *out, void *stream_)
+{
+    if (int rc = check_dims(batch, n)) return rc;
+    HIP_TRY(launch_rowmin(C, n, batch, v, out, reinterpret_cast<hipStream_t>(stream_)));
+    return 0;
+}
+
 int lapwarm_row_features_batched(const double *C, int batch, int n, const float *posenc, float *feat,
                                  float *topk16, void *workspace, size_t workspace_bytes, void *stream_)
 {
@@ -498,6 +505,25 @@ int lapwarm_min_trick(const double *C, int n, const double *u, double *v)
     int rc = lapwarm_colmin_batched(dC, 1, n, u ? du : nullptr, dv, ws, ws_bytes, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(v, dv, sizeof(double) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int lapwarm_row_min(const double *C, int n, const double *v, double *out)
+{
+    if (n <= 0) return -2;
+    if (n > 16384) return -5;
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t total = align_up(sizeof(double) * (size_t)n * n) + 2 * align_up(sizeof(double) * n);
+    if (g_arena.reserve(total) != hipSuccess) return -1;
+    Carver c{reinterpret_cast<unsigned char *>(g_arena.ptr), 0};
+    double *dC = c.take<double>((size_t)n * n);
+    double *dv = c.take<double>(n);
+    double *dout = c.take<double>(n);
+    HIP_TRY(hipMemcpy(dC, C, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
+    if (v) HIP_TRY(hipMemcpy(dv, v, sizeof(double) * n, hipMemcpyHostToDevice));
+    int rc = lapwarm_rowmin_batched(dC, 1, n, v ? dv : nullptr, dout, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -26,6 +26,8 @@ SIGNATURES = {
     "lapwarm_lapjv_dense": (ct.c_int, [c_dp, ct.c_int, c_ip, c_ip]),
     "lapwarm_row_features": (ct.c_int, [c_dp, ct.c_int, c_fp, c_fp]),
     "lapwarm_min_trick": (ct.c_int, [c_dp, ct.c_int, c_dp, c_dp]),
+    "lapwarm_row_min": (ct.c_int, [c_dp, ct.c_int, c_dp, c_dp]),
+    "lapwarm_rowmin_batched": (ct.c_int, [c_vp, ct.c_int, ct.c_int, c_vp, c_vp, c_vp]),
     "lapwarm_project_feasible": (ct.c_int, [c_dp, ct.c_int, c_dp, c_dp, ct.c_int, ct.c_double]),
     "lapwarm_reduce_costs": (ct.c_int, [c_dp, ct.c_int, c_dp, c_dp, ct.c_int, c_dp, c_dp]),
     "lapwarm_seeded_workspace_bytes": (ct.c_size_t, [ct.c_int, ct.c_int]),

@@ -46,6 +46,10 @@ int lapwarm_row_features(const double *C, int n, float *feat, float *topk16);
  * gnn/features.py:218). */
 int lapwarm_min_trick(const double *C, int n, const double *u, double *v);
 
+/* Row minima  out_i = min_j (C_ij - v_j)  (v NULL -> plain row minima): the `row_min` /
+ * `u_cap` sweeps of solvers/seed_baselines.py:29 and solvers/advanced_dual.py:29. */
+int lapwarm_row_min(const double *C, int n, const double *v, double *out);
+
 /* solvers/advanced_dual.py:14-36 `project_feasible`: u, v updated in place. */
 int lapwarm_project_feasible(const double *C, int n, double *u, double *v, int max_rounds, double tol);
 
@@ -95,6 +99,9 @@ size_t lapwarm_sweep_workspace_bytes(int batch, int n);
 /* out[b][j] = min_i (C[b][i][j] - u[b][i]); u may be NULL. */
 int lapwarm_colmin_batched(const double *C, int batch, int n, const double *u, double *out,
                            void *workspace, size_t workspace_bytes, void *stream);
+
+/* out[b][i] = min_j (C[b][i][j] - v[b][j]); v may be NULL. */
+int lapwarm_rowmin_batched(const double *C, int batch, int n, const double *v, double *out, void *stream);
 
 /* feat [batch][n][21] float32, topk16 [batch][n][16] float32 or NULL; posenc [n][8] float32 is
  * the table of gnn/features.py:21-31 (built once per n on the host). */

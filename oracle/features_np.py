@@ -11,6 +11,7 @@ Restates (paths relative to /root/reference):
   solvers/advanced_dual.py:14-36 project_feasible
   solvers/advanced_dual.py:39-53 reduce_costs
   solvers/advanced_dual.py:56-63 check_dual_feasible
+  solvers/seed_baselines.py:18-37 seed_row_col_minima
 """
 from __future__ import annotations
 
@@ -116,6 +117,14 @@ def reduce_costs(C, u, v, shift_nonneg: bool = True) -> np.ndarray:
         if lo < 0:
             R = R - lo
     return np.ascontiguousarray(R, dtype=np.float64)
+
+
+def seed_row_col_minima(C, project_rounds: int = 50):
+    """solvers/seed_baselines.py:18-37."""
+    C = np.asarray(C, dtype=np.float64)
+    u = C.min(axis=1).copy()
+    v = (C - u[:, None]).min(axis=0)
+    return project_feasible(C, u, v, max_rounds=project_rounds)
 
 
 def check_dual_feasible(C, u, v, tol: float = 1e-8) -> bool:

@@ -101,6 +101,26 @@ def test_dual_utilities_golden(features_cases):
         check_dual_feasible(np.zeros((4, 4)), np.ones(4), np.ones(4))
 
 
+def test_classical_seeds(features_cases):
+    """seed_row_col_minima is the reference's sweeps one for one: bit-identical to the NumPy
+    restatement; seed_noisy_optimal must return feasible duals whose seeded solve is optimal."""
+    import lap
+    from oracle import features_np
+    from solvers import check_dual_feasible, seed_noisy_optimal, seed_row_col_minima
+    z = features_cases
+    for key in [str(s) for s in z["labels"]]:
+        C = z[f"C__{key}"]
+        u, v = seed_row_col_minima(C)
+        uo, vo = features_np.seed_row_col_minima(C)
+        assert np.array_equal(u, uo) and np.array_equal(v, vo), key
+        assert check_dual_feasible(C, u, v, tol=1e-9)
+    C = z["C__uniform_n64"]
+    u, v = seed_noisy_optimal(C, noise_std=0.05, rng=np.random.default_rng(3))
+    assert check_dual_feasible(C, u, v, tol=1e-9)
+    x, y, cost = lap.lapjv_seeded(C, u, v)
+    assert abs(cost - lap.lapjv(C)[0]) < 1e-9
+
+
 @pytest.mark.parametrize("tag,H,L", [("h64l2", 64, 2), ("h192l4", 192, 4)])
 def test_onegnn_device_forward_golden(onegnn_cases, torch_cuda, tag, H, L):
     torch = torch_cuda
