@@ -134,6 +134,9 @@ int main(int argc, char **argv)
     const int max_n = argc > 1 ? atoi(argv[1]) : 256;
     const int reps = argc > 2 ? atoi(argv[2]) : 2;
     const int verbose = argc > 3 ? atoi(argv[3]) : 0;
+    const int gpu_repeat = getenv("PARITY_GPU_REPEAT") ? atoi(getenv("PARITY_GPU_REPEAT")) : 1;
+    const int repeat_min_n = getenv("PARITY_REPEAT_MIN_N") ? atoi(getenv("PARITY_REPEAT_MIN_N")) : 0;
+    const char *only = getenv("PARITY_ONLY");
     const char *fams[] = {"uniform", "int9", "int100", "tie", "sparse", "metric", "clustered", "twozero", "sparse_neg", "uniform1e8"};
     const char *kinds[] = {"zeros", "rowmin", "rowmin32", "noisy", "randu", "huge", "arr"};
     const int sizes[] = {1, 2, 3, 5, 8, 16, 33, 64, 100, 128, 200, 256, 400, 512, 777, 1024, 2048, 4096};
@@ -153,10 +156,30 @@ int main(int argc, char **argv)
                 for (int rep = 0; rep < r_eff; ++rep) {
                     make_family(fam, n, C);
                     make_seeds(kind, n, C, u, v);
+                    if (only) {  // PARITY_ONLY=fam:kind:n -- same random stream, solve just that case
+                        char key[96];
+                        snprintf(key, sizeof(key), "%s:%s:%d", fam, kind, n);
+                        if (strcmp(key, only)) continue;
+                    }
                     std::vector<long long> xo(n, -1), yo(n, -1), xg(n, -1), yg(n, -1);
                     jvo_stats st;
                     const int ro = jvo_lapjv_seeded_ex(C.data(), n, n, xo.data(), yo.data(), u.data(), v.data(), 1e-12, &st, nullptr, nullptr);
-                    const int rg = lapjv_seeded(C.data(), n, n, xg.data(), yg.data(), u.data(), v.data(), 1e-12);
+                    int rg = lapjv_seeded(C.data(), n, n, xg.data(), yg.data(), u.data(), v.data(), 1e-12);
+                    // PARITY_GPU_REPEAT=K (with PARITY_REPEAT_MIN_N): solve the same instance K times on
+                    // the GPU and stop at the first run that differs from the oracle (race hunting)
+                    for (int q = 1; q < ((n >= repeat_min_n) ? gpu_repeat : 1); ++q) {
+                        const bool ok_q = (ro == rg) && (ro != 0 || (!memcmp(xo.data(), xg.data(), sizeof(long long) * n) &&
+                                                                     !memcmp(yo.data(), yg.data(), sizeof(long long) * n)));
+                        if (!ok_q) {
+                            printf("  (differs at GPU repetition %d)\n", q - 1);
+                            break;
+                        }
+                        rg = lapjv_seeded(C.data(), n, n, xg.data(), yg.data(), u.data(), v.data(), 1e-12);
+                        if (q % 20 == 0) {
+                            printf("  ... %s %s n=%d repetition %d\n", fam, kind, n, q);
+                            fflush(stdout);
+                        }
+                    }
                     ++total;
                     if (ro == 0) branch_hist[st.branch]++;
                     if (ro == -3) ret_hist_m3++;
@@ -181,6 +204,7 @@ int main(int argc, char **argv)
             // cold solve
             if (strcmp(fam, "uniform1e8")) {
                 make_family(fam, n, C);
+                if (only) continue;  // (the stream stays in step; only the selected seeded case is solved)
                 std::vector<int> xo(n), yo(n), xg(n, -7), yg(n, -7);
                 const int ro = jvo_lapjv_dense(C.data(), n, xo.data(), yo.data(), nullptr);
                 const int rg = lapwarm_lapjv_dense(C.data(), n, xg.data(), yg.data());
