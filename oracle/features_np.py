@@ -37,8 +37,11 @@ def positional_encodings(n: int) -> np.ndarray:
     return out.astype(np.float32)
 
 
-def row_statistics(C: np.ndarray) -> np.ndarray:
-    """The 13 data-dependent columns, in fp64 (n, 13), before the float32 cast."""
+def row_statistics(C: np.ndarray, col_min: np.ndarray | None = None) -> np.ndarray:
+    """The 13 data-dependent columns, in fp64 (n, 13), before the float32 cast.
+
+    `col_min`: column minima of the FULL matrix when C is only a subset of its rows (large-n
+    spot checks); default: the minima of C itself, as in the reference."""
     C = np.asarray(C, dtype=np.float64)
     n, m = C.shape
     lo = C.min(axis=1)
@@ -68,7 +71,8 @@ def row_statistics(C: np.ndarray) -> np.ndarray:
     k_std = knear.std(axis=1)
 
     near_best = (C <= lo[:, None] * 1.1).sum(axis=1) / max(1, m)
-    col_min = C.min(axis=0)
+    if col_min is None:
+        col_min = C.min(axis=0)
     col_best = (C == col_min).sum(axis=1) / max(1, m)
     return np.stack([lo, hi, mean, std, mad, entropy, gap, competition, k_mean, k_std,
                      difficulty, near_best, col_best], axis=1)

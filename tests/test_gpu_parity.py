@@ -278,6 +278,47 @@ def test_large_n_pipeline_exact(torch_cuda, n):
     assert st[6] == so["scan_steps"] and st[4] == so["paths"] and st[7] == so["scan_elems"]
 
 
+def test_k5_dense_stages_n16384(torch_cuda):
+    """BASELINE config K5 (n=16384, top-16 refinement path): the dense stages on one instance.
+    Row features (128-KiB LDS row) against the NumPy oracle on sampled rows, u against the
+    PyTorch-CPU forward (fp32 cost tensor, top-k over 16384 columns) within the north-star 1e-5,
+    v-hat exact."""
+    torch = torch_cuda
+    from gnn import OneGNN
+    from gnn.features import min_trick_device, row_features_device
+    from oracle import features_np, one_gnn_ref
+    n = 16384
+    C = np.random.RandomState(42).uniform(0, 1, (n, n))
+    Cd = torch.from_numpy(C).cuda().unsqueeze(0)
+    feat, topk = row_features_device(Cd)
+    torch.cuda.synchronize()
+    got = feat[0].cpu().numpy()
+    rows = np.random.RandomState(7).choice(n, size=48, replace=False)
+    want = features_np.row_statistics(C[rows], col_min=C.min(axis=0)).astype(np.float32)
+    np.testing.assert_allclose(got[rows, :13], want, rtol=3e-6, atol=1e-9)
+    for col in (0, 1, 4, 6, 11, 12):
+        assert np.array_equal(got[rows, col], want[:, col]), col
+    assert np.array_equal(got[:, 13:], features_np.positional_encodings(n))
+    # the 16 smallest entries per row that the refinement consumes
+    assert np.array_equal(topk[0].cpu().numpy()[rows], features_np.topk_smallest(C[rows], 16).astype(np.float32))
+
+    sd = one_gnn_ref.init_state_dict(hidden=64, layers=2, seed=0)
+    model = OneGNN(21, hidden=64, layers=2)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    mask = torch.ones((1, n), dtype=torch.bool, device="cuda")
+    with torch.inference_mode():
+        u_gpu = model(feat, mask=mask, topk_values=topk)["u"][0]
+        u_ref = one_gnn_ref.forward(sd, feat.cpu(), torch.from_numpy(C).float().unsqueeze(0), mask.cpu())[0]
+    assert np.abs(u_gpu.cpu().numpy() - u_ref.numpy()).max() <= 1e-5
+    v = min_trick_device(Cd, u_gpu.unsqueeze(0))[0].cpu().numpy()
+    u64 = u_gpu.cpu().numpy().astype(np.float64)
+    want_v = np.full(n, np.inf)
+    for lo in range(0, n, 2048):  # (row blocks: the n x n temporary would be 2 GiB)
+        want_v = np.minimum(want_v, (C[lo:lo + 2048] - u64[lo:lo + 2048, None]).min(axis=0))
+    assert np.array_equal(v, want_v)
+
+
 def test_pipeline_mixed_families_end_to_end(torch_cuda):
     """K3-shaped (reduced batch): features + OneGNN + min-trick + seeded solve, all families.
     u/v within 1e-5 of the CPU forward; assignments bit-exact given the GPU's own (u, v)."""
