@@ -431,33 +431,26 @@ struct Solver {
                 double totv;
                 int totp;
                 {
-                    // one LDS round trip: lane l reads the slot of wave (l & 15); a 16-lane
-                    // butterfly gives the block total and the prefix over the earlier waves
+                    // one LDS round trip: lane l reads the slot of wave (l & 15); ONE inclusive
+                    // prefix-min scan along each row of 16 lanes (four DPP row_shr steps) holds both
+                    // answers: lane 15 = block total, lane wave-1 = minimum over the earlier waves
                     const int w = bc.lane & (kMaxWaves - 1);
-                    const double sv = (w < bc.nwaves) ? bc.ex->d[xp][w] : pos_inf();
-                    const int sp = (w < bc.nwaves) ? bc.ex->i[xp][w] : 0x7fffffff;
-                    double av = sv, pv = (w < bc.wave) ? sv : pos_inf();
-                    int ap = sp, pp = (w < bc.wave) ? sp : 0x7fffffff;
-#pragma unroll
-                    for (int m = 8; m >= 1; m >>= 1) {
-                        const double o1 = __shfl_xor(av, m, kWave);
-                        const int o2 = __shfl_xor(ap, m, kWave);
-                        if (pair_less(o1, o2, av, ap)) {
-                            av = o1;
-                            ap = o2;
+                    double av = (w < bc.nwaves) ? bc.ex->d[xp][w] : pos_inf();
+                    int ap = (w < bc.nwaves) ? bc.ex->i[xp][w] : 0x7fffffff;
+                    scan_step_min_pair<kDppRowShr1, 0xf>(av, ap);
+                    scan_step_min_pair<kDppRowShr2, 0xf>(av, ap);
+                    scan_step_min_pair<kDppRowShr4, 0xf>(av, ap);
+                    scan_step_min_pair<kDppRowShr8, 0xf>(av, ap);
+                    totv = readlane_f64(av, kMaxWaves - 1);
+                    totp = __builtin_amdgcn_readlane(ap, kMaxWaves - 1);
+                    if (bc.wave > 0) {
+                        const int wl = uni(bc.wave) - 1;
+                        const double pv = readlane_f64(av, wl);
+                        const int pp = __builtin_amdgcn_readlane(ap, wl);
+                        if (pair_less(pv, pp, runv, runp)) {
+                            runv = pv;
+                            runp = pp;
                         }
-                        const double o3 = __shfl_xor(pv, m, kWave);
-                        const int o4 = __shfl_xor(pp, m, kWave);
-                        if (pair_less(o3, o4, pv, pp)) {
-                            pv = o3;
-                            pp = o4;
-                        }
-                    }
-                    totv = uni(av);
-                    totp = uni(ap);
-                    if (pair_less(pv, pp, runv, runp)) {
-                        runv = pv;
-                        runp = pp;
                     }
                 }
                 STAMP_FI(3, tfc);
