@@ -34,6 +34,7 @@ __device__ __forceinline__ double uni(double x)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+__device__ __forceinline__ unsigned umin_u32(unsigned a, unsigned b) { return a < b ? a : b; }
 __device__ __forceinline__ double pos_inf() { return __longlong_as_double(0x7ff0000000000000LL); }
 
 __device__ __forceinline__ double dmin(double a, double b) { return (b < a) ? b : a; }

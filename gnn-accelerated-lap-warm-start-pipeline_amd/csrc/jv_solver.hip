@@ -556,7 +556,7 @@ struct Solver {
             STAMPR(tr0);
             // a row index must be a matched row; anything else means corrupted state -- never
             // turn it into a global address
-            if (head_i < 0 || head_i >= n || head_j < 0 || head_j >= n) {
+            if ((unsigned)head_i >= (unsigned)n || (unsigned)head_j >= (unsigned)n) {
                 err = 6;
                 break;
             }
@@ -564,13 +564,10 @@ struct Solver {
             double c[CH];
 #pragma unroll
             for (int r = 0; r < CH; ++r) {
-                // never form a global address from an out-of-range column (would be a logic bug:
-                // flag it instead of faulting)
-                int jc = jr[r];
-                if ((unsigned)jc >= (unsigned)n) {
-                    ctrl->err = 7;
-                    jc = 0;
-                }
+                // never form a global address from an out-of-range column: a clamp (one
+                // instruction; the step is instruction-issue bound) rather than a test and branch.
+                // jr[] only ever holds entries of order[], so the clamp is a no-op by construction.
+                const unsigned jc = umin_u32((unsigned)jr[r], (unsigned)(n - 1));
                 c[r] = row[jc];  // unconditional: all gathers in flight
             }
             double c_head = row[head_j];
