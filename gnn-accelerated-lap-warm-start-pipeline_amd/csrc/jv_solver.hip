@@ -387,10 +387,6 @@ struct Solver {
         double level = 0.0;
         int guard = 0;
         while (target < 0) {
-            if (++guard > 2 * n + 4) {
-                err = 1;
-                break;
-            }
             if (lo == hi) {
                 // ---------------- minima collection over positions [lo, n); dk[] is current.
                 // Scan of the lexicographic (distance, position) minimum = "the first position that
@@ -572,6 +568,14 @@ struct Solver {
             }
             double c_head = row[head_j];
             const int par = step_id & 1;
+            // per-step bookkeeping goes here, in the shadow of the gathers, not behind the barrier
+            step_id++;
+            scan_steps++;
+            scan_elems += (long long)(n - hi);
+            if (++guard > 2 * n + 4) {
+                err = 1;
+                break;
+            }
             // While the gathers are in flight: (a) the next queued SCAN column, if there is one,
             // is already known -- fetch it and its row now; (b) the owner of position hi publishes
             // the column sitting there (what a single tie event will displace).
@@ -680,9 +684,6 @@ struct Solver {
                 seen1 = tot;
             else
                 seen0 = tot;
-            scan_steps++;
-            scan_elems += (long long)(n - hi);
-            step_id++;
             if (cnt == 0) {
                 STAMP_INC(5);
                 ++lo;
