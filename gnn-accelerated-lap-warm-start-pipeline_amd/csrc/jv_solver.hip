@@ -482,6 +482,13 @@ struct Solver {
                 for (int r = 0; r < CH; ++r) prevcol[r] = (prevpos[r] >= 0) ? order[prevpos[r]] : 0;
                 const int min_col = uni(order[totp]);  // column of the global minimum (uniform)
                 if (tie) ctrl->tie_find = find_seq;
+                // The matched row of the winning column decides whether the path ends here.  It MUST
+                // be read before the barrier: once the waves are released, a fast wave can finish
+                // the path and thread 0's backtrack (augment_all) rewrites y[] -- a slow wave that
+                // looked y[min_col] up after the barrier could then see the column as matched, carry
+                // on alone and corrupt the search (found with tools/stress_determinism.py: ~1 run
+                // in 100-300 ended in a consistency guard; 0 in 900 with this order).
+                const int min_row_raw = y[min_col];
                 STAMP_FI(4, tfd);
                 STAMP_ADD(11, tfd, tfc);
                 __syncthreads();
@@ -507,7 +514,7 @@ struct Solver {
                     hi = lo + 1;
                     level = totv;
                     head_j = min_col;
-                    head_i = uni(y[min_col]);
+                    head_i = uni(min_row_raw);
                     target = (head_i < 0) ? head_j : -1;
                     STAMP_FI(6, tff);
                     STAMP_ADD(13, tff, tfe);
