@@ -55,6 +55,8 @@ struct Ctrl {
     int nfree;
     int err;
     int head_j, head_i;
+    int free_pos[2];  // smallest position of a tie event whose column is FREE, per step parity
+                      // (INT_MAX: none); lets the ordered replay skip the y[] lookup per event
 };
 
 constexpr int kSentinelIdx = 0x7ffffffe;  // the LARGE sentinel of the ARR scan (index -1 in the reference)
@@ -295,6 +297,10 @@ struct Solver {
         const int lane = bc.lane;
         uint32_t *evb = this->evb + (size_t)par * Wpad;
         int target = -1;
+        // the first event (in position order) whose column is free ends the scan (lapjv.cpp:200-201);
+        // its finder recorded the position, so no event needs its y[] looked up here
+        const int fp = uni(ctrl->free_pos[par]);
+        if (fp != 0x7fffffff && lane == 0) ctrl->free_pos[par] = 0x7fffffff;
         for (int wbase = 0; wbase < W; wbase += kWave) {
             const int idx = wbase + lane;
             uint32_t ew = 0;
@@ -312,7 +318,7 @@ struct Solver {
                     e &= e - 1;
                     const int k = ((wbase + l) << 5) + bit;
                     const int j = order[k];
-                    if (y[j] < 0) {
+                    if (k == fp) {
                         target = j;
                     } else {
                         const int a = order[hi];
@@ -650,6 +656,12 @@ struct Solver {
                             ++my_events;
                             const int k = b0 + r;
                             atomicOr(&evb[par * Wpad + (k >> 5)], 1u << (k & 31));
+                            int yj;
+                            if constexpr (CACHE_Y)
+                                yj = yr[r];
+                            else
+                                yj = y[jr[r]];
+                            if (yj < 0) atomicMin(&ctrl->free_pos[par], k);
                         }
                     }
                 }
@@ -731,6 +743,7 @@ struct Solver {
                     }
                 }
                 if (sl.i < 0) {
+                    if (bc.tid == 0) ctrl->free_pos[par] = 0x7fffffff;  // (its finder recorded it)
                     target = sl.j;
                     break;
                 }
@@ -1246,6 +1259,8 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         s.ctrl->tie_find = 0;
         s.ctrl->ev_total[0] = 0;
         s.ctrl->ev_total[1] = 0;
+        s.ctrl->free_pos[0] = 0x7fffffff;
+        s.ctrl->free_pos[1] = 0x7fffffff;
         s.ctrl->err = 0;
         s.ctrl->nfree = 0;
         s.ctrl->hi = 0;
