@@ -390,7 +390,7 @@ def test_run_to_run_determinism_under_concurrent_traffic(torch_cuda):
     side = torch.cuda.Stream()
     junk = torch.empty((32, 1024, 1024), device="cuda")
     first = None
-    for rep in range(12):
+    for rep in range(60):  # (a path-end race once needed ~100-300 repetitions to show: tools/stress_determinism.py)
         if rep % 2:
             with torch.cuda.stream(side):
                 for _ in range(10):
