@@ -27,6 +27,8 @@ for r in range(reps):
                 junk.mul_(1.0001)
     x, y, ret, st = pipe.seeded_batch(C, u, v)
     torch.cuda.synchronize()
+    if r and r % 500 == 0:
+        print(f"  progress: {r} repetitions, {bad} bad", flush=True)
     xr, rr = x.cpu().numpy(), ret.cpu().numpy()
     if x0 is None:
         x0 = xr
