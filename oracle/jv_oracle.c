@@ -10,11 +10,13 @@
  *
  * Parity pin: this file is validated against (a) the reference's own sources
  * compiled unmodified into oracle/_ref/ (see oracle/Makefile) on thousands of
- * seeded cases (tests/test_oracle_vs_ref.py, run where /root/reference exists),
+ * seeded cases (tools/find_arr_cases.py and tests/golden/make_golden.py, run where
+ * /root/reference exists),
  * (b) the golden vectors committed under tests/golden/ (generated from the
  * reference by tests/golden/make_golden.py) and (c) the reference's known-answer
- * cases in LAP/lap/tests/test_lapjv.py:60-129 (restated as data in
- * tests/test_oracle_known_answers.py).
+ * cases in LAP/lap/tests/test_lapjv.py:60-148 (restated as data in
+ * tests/test_host_logic.py: KNOWN_SQUARE / KNOWN_INF; checked by tests/test_oracle_golden.py
+ * and test_host_logic.py::test_oracle_reproduces_reference_known_answers).
  *
  * What is restated (reference paths relative to /root/reference):
  *   seeded solve        LAP/_lapjv_cpp/lapjv_seeded.cpp:19-173

@@ -25,6 +25,7 @@ REF = Path("/root/reference")
 OUT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+from oracle import jv as oracle_jv  # noqa: E402
 from oracle import ref as ref_lib  # noqa: E402
 
 
@@ -99,13 +100,21 @@ def seeds(kind: str, C: np.ndarray, seed: int):
     raise KeyError(kind)
 
 
+# (n, seed, scale, sigma) of instances on which the micro-ARR step fires (1 or 2 times)
+ARR_SEEDS = [(8, 200030, 1e8, 0.02), (8, 200064, 1e8, 0.02), (8, 200074, 1e8, 0.02),
+             (16, 200375, 1e8, 0.02), (16, 200413, 1e8, 0.02), (16, 200499, 1e8, 0.02),
+             (32, 200789, 1e8, 0.02), (32, 201194, 1e8, 0.02), (32, 201917, 1e8, 0.02),
+             (8, 203590, 1e9, 0.02), (8, 203604, 1e9, 0.02), (8, 203605, 1e9, 0.02)]
+
+
 # --------------------------------------------------------------------------- seeded solver
 def make_seeded():
     cases = []
 
     def add(label, C, u, v, eps=1e-12):
         ret, x, y = ref_lib.seeded_raw(C, u, v, eps)
-        cases.append(dict(label=label, C=C, u=u, v=v, eps=eps, ret=ret, x=x, y=y))
+        fired = oracle_jv.seeded_raw(C, u, v, eps)[3]["arr_fired"]  # the reference has no counter
+        cases.append(dict(label=label, C=C, u=u, v=v, eps=eps, ret=ret, x=x, y=y, arr_fired=fired))
 
     # the reference's two print-style demos (LAP/test_seeded.py:9-25, LAP/demo_seeded.py:18-37)
     add("demo3x3/zeros", np.array([[4., 1., 3.], [2., 0., 5.], [3., 2., 2.]]), np.zeros(3), np.zeros(3))
@@ -143,6 +152,14 @@ def make_seeded():
             C = family("uniform1e8", n, seed)
             u, v = seeds("arr", C, seed)
             add(f"uniform1e8/n{n}/arr{rep}", C, u, v)
+    # micro-ARR FIRING cases (lapjv_seeded.cpp:136-159): found by tools/find_arr_cases.py with the
+    # oracle's arr_fired counter, confirmed against oracle/_ref, frozen here by seed
+    for n, s, scale, sigma in ARR_SEEDS:
+        rs = np.random.RandomState(s)
+        C = rs.uniform(0, scale, size=(n, n))
+        u = C.min(1) + np.random.RandomState(s + 7919).normal(0, sigma * scale, n)
+        v = (C - u[:, None]).min(0)
+        add(f"arrfire/n{n}/s{s}", C, u, v)
     # ret == -3: sparse fill (1e6) with noise at that scale
     for n in (8, 32, 64):
         for rep in range(4):
@@ -176,6 +193,7 @@ def make_seeded():
         ret=np.array([c["ret"] for c in cases], dtype=np.int64),
         x=np.concatenate([c["x"] for c in cases]),
         y=np.concatenate([c["y"] for c in cases]),
+        arr_fired=np.array([c["arr_fired"] for c in cases], dtype=np.int64),
     )
 
 

@@ -70,6 +70,57 @@ def test_reference_known_answers():
         assert cost[range(cost.shape[0]), ret[1]].sum() == ret[0]
 
 
+def test_reference_known_answer_with_inf_entries():
+    """LAP/lap/tests/test_lapjv.py:132-148 (test_sparse_square): inf entries go through the cold
+    ARR path's inf/NaN handling on the device."""
+    import lap
+    from test_host_logic import KNOWN_INF
+    cost, (opt, ex, ey) = KNOWN_INF
+    ret = lap.lapjv(cost)
+    assert ret[0] == opt
+    assert list(ret[1]) == ex and list(ret[2]) == ey
+
+
+def test_micro_arr_firing_cases(seeded_cases, torch_cuda):
+    """Instances on which the micro-ARR step fires (lapjv_seeded.cpp:136-159; found on CPU with
+    the oracle's counter, confirmed against the reference build, frozen in make_golden.py):
+    assignments bit-exact vs the reference AND the kernel reports the same number of firings."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    fired = seeded_cases.z["arr_fired"]
+    ks = [k for k in range(len(seeded_cases)) if fired[k] > 0]
+    assert len(ks) >= 10
+    pipe = WarmStartPipeline(OneGNN(21), "cuda:0")
+    for k in ks:
+        c = seeded_cases.case(k)
+        x, y, ret, stats = pipe.seeded_batch(torch.from_numpy(c["C"][None]).cuda(),
+                                             torch.from_numpy(c["u"][None]).cuda(),
+                                             torch.from_numpy(c["v"][None]).cuda(), c["eps"])
+        torch.cuda.synchronize()
+        assert int(ret[0]) == c["ret"] == 0, c["label"]
+        assert int(stats[0, 3]) == int(fired[k]), (c["label"], int(stats[0, 3]), int(fired[k]))
+        assert np.array_equal(x[0].cpu().numpy(), c["x"]), c["label"]
+        assert np.array_equal(y[0].cpu().numpy(), c["y"]), c["label"]
+
+
+def test_compute_row_features_torch_matches_host_entry(features_cases, torch_cuda):
+    """gnn/features.py:246-351's device entry: CUDA tensors in fp64 and fp32 give
+    exactly what compute_row_features gives on the same (widened) values."""
+    torch = torch_cuda
+    from gnn import compute_row_features, compute_row_features_torch
+    z = features_cases
+    for key in ("uniform_n64", "sparse_n200", "tie_n64", "metric_n9"):
+        C = z[f"C__{key}"]
+        want = compute_row_features(C)
+        got64 = compute_row_features_torch(torch.from_numpy(C).cuda())
+        assert got64.is_cuda and got64.dtype == torch.float32
+        assert np.array_equal(got64.cpu().numpy(), want), key
+        C32 = C.astype(np.float32)
+        got32 = compute_row_features_torch(torch.from_numpy(C32).cuda())
+        assert np.array_equal(got32.cpu().numpy(), compute_row_features(C32.astype(np.float64))), key
+    assert tuple(compute_row_features_torch(torch.zeros((0, 0)).cuda()).shape) == (0, 0)
+
+
 def test_row_features_golden(features_cases):
     from gnn import compute_row_features
     z = features_cases
@@ -344,6 +395,41 @@ def test_pipeline_mixed_families_end_to_end(torch_cuda):
         assert r == ret[b], fams[b]
         if r == 0:
             assert np.array_equal(xo, x[b]) and np.array_equal(yo, y[b]), fams[b]
+
+
+def test_k3_config_full_size(torch_cuda):
+    """BASELINE configs[2] (K3) at its stated size: batch=32, n=2048, 8 each uniform / sparse /
+    metric / clustered, OneGNN H=192 L=4.  u/v within 1e-5 of the CPU forward on one instance per
+    family; x/y bit-exact and control-flow counters equal to the oracle's on all 32."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    from oracle import jv, one_gnn_ref
+    from solvers.generators import mixed_batch
+    B, n = 32, 2048
+    Cs, fams = mixed_batch(B, n, seed=1234)
+    assert sorted(set(fams)) == ["clustered", "metric", "sparse", "uniform"]
+    torch.manual_seed(0)
+    model = OneGNN(21, hidden=192, layers=4).eval()
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    out = WarmStartPipeline(model, "cuda:0").solve_batch(torch.from_numpy(Cs).cuda())
+    torch.cuda.synchronize()
+    u, v = out["u"].cpu().numpy(), out["v"].cpu().numpy()
+    x, y, ret = out["x"].cpu().numpy(), out["y"].cpu().numpy(), out["ret"].cpu().numpy()
+    stats = out["stats"].cpu().numpy()
+    for f in sorted(set(fams)):
+        b = fams.index(f)
+        ur, vr = one_gnn_ref.predict(sd, Cs[b])
+        assert np.abs(u[b] - ur).max() <= 1e-5, (f, np.abs(u[b] - ur).max())
+        scale = max(1.0, float(np.abs(vr).max()))
+        assert np.abs(v[b] - vr).max() <= 1e-5 * scale, (f, np.abs(v[b] - vr).max())
+    names = ["branch", "tight_edges", "free_rows", "arr_fired", "paths", "finds", "scan_steps", "scan_elems",
+             "init_elems", "colred_elems", "transfer_rows", "arr_iters"]
+    for b in range(B):
+        r, xo, yo, st = jv.seeded_raw(Cs[b], u[b].astype(np.float64), v[b])
+        assert r == ret[b] == 0, (b, fams[b], r, ret[b])
+        assert np.array_equal(xo, x[b]) and np.array_equal(yo, y[b]), (b, fams[b])
+        for q, name in enumerate(names):
+            assert stats[b, q] == st[name], (b, fams[b], name, stats[b, q], st[name])
 
 
 @pytest.mark.parametrize("n,hint", [(1024, 1024), (1024, 512), (1024, 256), (2048, 1024), (2048, 512)])

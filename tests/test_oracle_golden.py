@@ -35,6 +35,18 @@ def test_seeded_fixtures_cover_projection_and_infeasible(seeded_cases):
     assert fired > 20
 
 
+def test_seeded_fixtures_cover_micro_arr_firing(seeded_cases):
+    """lapjv_seeded.cpp:136-159 fires in >= 10 fixtures (x, y there come from the reference build)."""
+    want = seeded_cases.z["arr_fired"]
+    ks = [k for k in range(len(seeded_cases)) if want[k] > 0]
+    assert len(ks) >= 10 and max(want) >= 2
+    for k in ks:
+        c = seeded_cases.case(k)
+        ret, x, y, st = jv.seeded_raw(c["C"], c["u"], c["v"], c["eps"])
+        assert ret == 0 and st["arr_fired"] == want[k] and st["branch"] == 1, c["label"]
+        assert np.array_equal(x, c["x"]) and np.array_equal(y, c["y"]), c["label"]
+
+
 def test_cold_solver_bit_exact(cold_cases):
     for k in range(len(cold_cases)):
         c = cold_cases.case(k)
