@@ -31,6 +31,10 @@
 //     a double-buffered LDS slot, every thread advances the uniform state from it, and only the
 //     owner of the affected position touches order[].  Steps with several events fall back to
 //     the ordered replay by wave 0.
+#include <stdlib.h>
+#include <string.h>
+
+#include "cols_search.hpp"
 #include "device_utils.hpp"
 #include "jv_solver.hpp"
 
@@ -42,7 +46,7 @@ struct EventSlot {
     int j, p, i, a;  // event column, its position, its matched row (-1: free), column at order[hi]
 };
 
-struct Ctrl {
+struct alignas(16) Ctrl {
     double level;
     EventSlot slot[2];
     int hi;
@@ -97,6 +101,8 @@ __device__ __forceinline__ unsigned long long stamp_now()
 template <int CH, int LDSL, int TB>
 struct Solver {
     static constexpr bool LDS_STATE = LDSL > 0;
+    static constexpr bool COLS = LDSL >= 3;   // column-owned search (labels never move between threads)
+    static constexpr bool VEC2 = LDSL == 4;   // ... with column pairs per thread (16-byte row loads; n even)
     static constexpr int kCacheLimit = (TB <= 256) ? 16 : 4;   // positions per thread whose duals fit in registers
     static constexpr int kCacheLimitY = (TB <= 256) ? 16 : 2;
     // problem
@@ -105,6 +111,8 @@ struct Solver {
     // state
     double *dist, *v;
     int *order, *pred, *y, *x, *fr;
+    cols::Layout clay;  // column-owned search (LDSL >= 3): cols_search.hpp
+    cols::Ctl *cctl;
     uint32_t *evt, *sbits, *used;
     uint32_t *evb;  // tie-event bitmap of a relax step, TWO copies selected by the step parity: the
                     // post phase of step t clears bits while pass t+1 may already be setting its own
@@ -144,7 +152,7 @@ struct Solver {
     //     moved B on); hops only go up, so every slot is resolved independently.
     // Both parts are data-parallel over the lanes of wave 0.  A tie BEFORE the last strict event
     // (rare) takes the serial loop.
-    __device__ __forceinline__ void replay_find(int lo)
+    __device__ __forceinline__ void replay_find(int lo, double level_in)
     {
         const int lane = bc.lane;
         // ---- 1. ordered event list: evl[i] = position | strict << 31
@@ -280,7 +288,9 @@ struct Solver {
         }
         const int target = (best >= 0) ? order[best] : -1;
         const int head_j = order[lo];
-        const double level = dist[head_j];
+        // position-owned search: dist[] is indexed by column; column-owned search: dist[] holds the
+        // distances in POSITION order and the caller passes the level (the collection's minimum)
+        const double level = COLS ? level_in : dist[head_j];
         const int head_i = y[head_j];
         if (lane == 0) {
             ctrl->hi = hi;
@@ -532,7 +542,7 @@ struct Solver {
                         if (sb) atomicOr(&sbits[wordi], sb << shift);
                     }
                     __syncthreads();
-                    if (bc.wave == 0) replay_find(lo);
+                    if (bc.wave == 0) replay_find(lo, 0.0);
                     __syncthreads();
                     hi = uni(ctrl->hi);
                     target = uni(ctrl->target);
@@ -811,21 +821,49 @@ struct Solver {
     {
         for (int f = 0; f < n_free && !err; ++f) {
             const int start = uni(fr[f]);
-            const int target = find_path(start);
+            if ((unsigned)start >= (unsigned)n) {
+                err = 2;
+                break;
+            }
+            int target;
+            if constexpr (COLS) {
+                // ends with a barrier (pred[] is dumped at the end)
+                target = uni(cols::search_path<CH, VEC2, TB>(clay, start));
+                if (target < 0) {
+                    err = uni(cctl->err);
+                    if (!err) err = 2;
+                }
+            } else {
+                target = find_path(start);
+            }
             if (err) break;
             if (bc.tid == 0) {
+                // a corrupted chain must end in a return code, never in an out-of-range access
                 int j = target, i = -1, hops = 0;
+                bool ok = true;
                 while (i != start && hops <= n) {
+                    if ((unsigned)j >= (unsigned)n) {
+                        ok = false;
+                        break;
+                    }
                     i = pred[j];
+                    if ((unsigned)i >= (unsigned)n) {
+                        ok = false;
+                        break;
+                    }
                     y[j] = i;
                     const int prev = x[i];
                     x[i] = j;
                     j = prev;
                     ++hops;
                 }
-                if (i != start) ctrl->err = 3;
+                if (!ok || i != start) ctrl->err = 3;
             }
             __syncthreads();
+            if (uni(ctrl->err)) {  // uniform: read after the barrier
+                err = 3;
+                break;
+            }
         }
     }
 
@@ -1197,6 +1235,17 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         s.evl = p.g_evl + (size_t)b * n;
         s.tmpcol = p.g_tmpcol + (size_t)b * (n + 2);
     }
+    if constexpr (LDSL >= 3) {
+        cur = smem + ((size_t)(cur - smem) + 15) / 16 * 16;
+        s.cctl = reinterpret_cast<cols::Ctl *>(cur);
+        s.clay.ctl = (int)(cur - smem);
+        cur += sizeof(cols::Ctl);
+        s.clay.qdesc = (int)(cur - smem);
+        cur += sizeof(cols::QDesc) * n;
+        s.clay.pos = (int)(cur - smem);
+        cur += sizeof(int) * n;
+        cur = smem + ((size_t)(cur - smem) + 15) / 16 * 16;
+    }
     if constexpr (LDSL > 0) {
         s.dist = reinterpret_cast<double *>(cur);
         cur += sizeof(double) * n;
@@ -1231,6 +1280,24 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
     s.C = p.C + (size_t)b * n * n;
     s.n = n;
     s.W = W;
+    if constexpr (LDSL >= 3) {
+        auto off = [&](const void *ptr) { return (int)(reinterpret_cast<const unsigned char *>(ptr) - smem); };
+        s.clay.C = s.C;
+        s.clay.n = n;
+        s.clay.W = W;
+        s.clay.Wpad = Wpad;
+        s.clay.dist = off(s.dist);
+        s.clay.v = off(s.v);
+        s.clay.order = off(s.order);
+        s.clay.pred = off(s.pred);
+        s.clay.y = off(s.y);
+        s.clay.evt = off(s.evt);
+        s.clay.sbits = off(s.sbits);
+        s.clay.evb = off(s.evb);
+        s.clay.evl = off(s.evl);
+        s.clay.tmpcol = off(s.tmpcol);
+        s.clay.ex = off(ex);
+    }
     s.scan_elems = s.init_elems = s.colred_elems = 0;
     s.paths = s.finds = s.scan_steps = s.arr_iters = s.transfer_rows = s.arr_fired = 0;
     s.step_id = 1;
@@ -1255,6 +1322,9 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         return;
     }
 
+    if constexpr (LDSL >= 3) {
+        if (tid == 0) cols::ctl_init(s.cctl);
+    }
     if (tid == 0) {
         s.ctrl->tie_find = 0;
         s.ctrl->ev_total[0] = 0;
@@ -1342,11 +1412,19 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
             st[1] = tight_total;
             st[2] = (branch == kBranchFallback || branch == kBranchCold) ? nf : free_after_greedy;
             st[3] = s.arr_fired;
-            st[4] = s.paths;
-            st[5] = s.finds;
-            st[6] = s.scan_steps;
-            st[7] = s.scan_elems;
-            st[8] = s.init_elems;
+            if constexpr (LDSL >= 3) {  // the column-owned search keeps its counters in LDS
+                st[4] = s.cctl->paths;
+                st[5] = s.cctl->finds;
+                st[6] = s.cctl->scan_steps;
+                st[7] = s.cctl->scan_elems;
+                st[8] = s.cctl->init_elems;
+            } else {
+                st[4] = s.paths;
+                st[5] = s.finds;
+                st[6] = s.scan_steps;
+                st[7] = s.scan_elems;
+                st[8] = s.init_elems;
+            }
             st[9] = s.colred_elems;
             st[10] = s.transfer_rows;
             st[11] = s.arr_iters;
@@ -1357,7 +1435,11 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
             st[15] = 0;
             for (int q = 16; q < kStatsPerInstance; ++q) st[q] = 0;
 #ifdef LAPWARM_STAMPS
-            for (int q = 0; q < 16; ++q) st[16 + q] = s.stamps[q];
+            if constexpr (LDSL >= 3) {
+                for (int q = 0; q < 16; ++q) st[16 + q] = s.cctl->stamps[q];
+            } else {
+                for (int q = 0; q < 16; ++q) st[16 + q] = s.stamps[q];
+            }
 #endif
         }
     }
@@ -1376,7 +1458,10 @@ hipError_t launch_one(const SolverParams &p, int threads, size_t lds_bytes, hipS
 
 }  // namespace
 
-// level 2: every array in LDS; 1: x and the free-row list in global memory; 0: all global
+// level 4: as 3 with column pairs per thread (n even); level 3: column-owned search, every
+// array in LDS plus pos[] and the SCAN-list entries;
+// 2: position-owned search, every array in LDS; 1: x and the free-row list in global memory;
+// 0: all global
 size_t solver_lds_bytes(int n, int ch, int level)
 {
     const int W = (n + 31) >> 5;
@@ -1385,11 +1470,23 @@ size_t solver_lds_bytes(int n, int ch, int level)
     size_t bytes = sizeof(BlockExchange) + sizeof(Ctrl) + sizeof(uint32_t) * (size_t)Wpad * 5;
     if (level >= 1) bytes += (size_t)n * (2 * sizeof(double) + 5 * sizeof(int)) + 2 * sizeof(int);
     if (level >= 2) bytes += (size_t)n * 2 * sizeof(int);
+    if (level >= 3) bytes += sizeof(cols::Ctl) + (size_t)n * (sizeof(cols::QDesc) + sizeof(int)) + 32;  // + alignment slack
     return bytes;
+}
+
+static bool legacy_search_forced()
+{
+    static const bool forced = [] {
+        const char *e = getenv("LAPWARM_SEARCH");
+        return e && strcmp(e, "legacy") == 0;
+    }();
+    return forced;
 }
 
 int solver_lds_level(int n, int ch)
 {
+    if (!legacy_search_forced() && solver_lds_bytes(n, ch, 3) <= kLdsBudgetBytes)
+        return (n % 2 == 0 && ch >= 2) ? 4 : 3;  // 4 = 3 with column pairs (16-byte row loads)
     if (solver_lds_bytes(n, ch, 2) <= kLdsBudgetBytes) return 2;
     if (solver_lds_bytes(n, ch, 1) <= kLdsBudgetBytes) return 1;
     return 0;
@@ -1432,10 +1529,14 @@ hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t st
 #define LAPWARM_CASE(CHV)                                                               \
     case CHV:                                                                           \
         if (threads <= 256) {                                                           \
+            if (level == 4) return launch_one<(CHV >= 2 ? CHV : 2), 4, 256>(p, threads, lds, stream); \
+            if (level == 3) return launch_one<CHV, 3, 256>(p, threads, lds, stream);    \
             if (level == 2) return launch_one<CHV, 2, 256>(p, threads, lds, stream);    \
             if (level == 1) return launch_one<CHV, 1, 256>(p, threads, lds, stream);    \
             return launch_one<CHV, 0, 256>(p, threads, lds, stream);                    \
         }                                                                               \
+        if (level == 4) return launch_one<(CHV >= 2 ? CHV : 2), 4, 1024>(p, threads, lds, stream); \
+        if (level == 3) return launch_one<CHV, 3, 1024>(p, threads, lds, stream);       \
         if (level == 2) return launch_one<CHV, 2, 1024>(p, threads, lds, stream);       \
         if (level == 1) return launch_one<CHV, 1, 1024>(p, threads, lds, stream);       \
         return launch_one<CHV, 0, 1024>(p, threads, lds, stream);
@@ -1460,7 +1561,7 @@ bool solver_needs_global_state(int n)
         const int l = solver_lds_level(n, c);
         if (l < worst) worst = l;
     }
-    return worst < 2;
+    return worst < 2;  // levels 2, 3 and 4 keep everything in LDS
 }
 
 }  // namespace lapwarm

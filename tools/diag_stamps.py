@@ -20,7 +20,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 st = st.cpu().numpy()
 print('ret nonzero:', int((ret != 0).sum()), 'err slots:', st[:,12].tolist()[:8])
-names = ["find", "relax:issue loads", "relax:wait+compute+publish", "relax:barrier", "relax:post", "n cnt0", "n cnt1", "n cnt>=2", "path init"]
+names = ["find", "relax:issue loads", "relax:wait+compute+publish", "relax:barrier", "relax:post", "n cnt0", "n cnt1", "n slow", "path end"]
 for f in ("uniform", "sparse", "clustered"):
     idx = [b for b in range(B) if fams[b] == f]
     s = st[idx].mean(0)
@@ -34,8 +34,13 @@ for f in ("uniform", "sparse", "clustered"):
         else:
             per = cyc[k] / (s[5] if k == 0 else (s[4] if k == 8 else s[6]))
             print(f"   {nm:28s} {cyc[k]/1e6:8.2f} Mcycles  ({100*cyc[k]/total_cyc:5.1f}%)  {per:8.0f} cycles each")
-    fn = ["find:pre-B1", "find:B1 wait", "find:flags+atomics", "find:B2 wait", "find:replay(w0)", "find:B3 wait"]
+    # column-owned search (r02): 9 scatter+B1, 10 scan..B2, 11 classify..B3, 12 apply/replay..B4+relabel, 13 path end
+    fn = ["find:scatter+B1", "find:scan..B2", "find:classify..B3", "find:apply..relabel"]
     for k, nm in enumerate(fn):
         print(f"      {nm:24s} {s[16+9+k]/s[5]:8.0f} cycles per find")
-    print(f"      events per find          {s[16+15]/s[5]:8.1f}")
+    print(f"      path end (dump+barrier)  {s[16+8]/s[4]:8.0f} cycles per path")
+    c0, c1, c2 = max(cyc[5], 1), max(cyc[6], 1), max(cyc[7], 1)
+    post2 = s[16+4] - s[16+13] - s[16+14]
+    print(f"      post | cnt0 {s[16+13]/c0:7.0f}  cnt1 {s[16+14]/c1:7.0f}  slow path (free/multi) {post2/c2:7.0f} cycles each")
+    print(f"      tie finds / finds        {s[16+15]/s[5]:8.3f}")
     print(f"   stamped total {total_cyc/1e6:.1f} Mcycles -> {total_cyc/ (tot_ms*1e-3) / 1e9:.2f} GHz-equivalent")
