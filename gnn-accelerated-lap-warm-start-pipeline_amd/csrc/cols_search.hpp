@@ -76,7 +76,7 @@ struct alignas(16) Rec {
 struct alignas(16) Ctl {
     Rec rec[2][kRecCap];    // per step parity, slot = arrival order
     alignas(16) int res[4];  // outcome of a multi-event replay: hi, target, label moves, error
-    QDesc resq[2];           // ... and the SCAN-list entries at lo+1 and lo+2 after it
+    QDesc resq[3];           // ... and the SCAN-list entries at lo+1 .. lo+3 after it
     int apub[kRecCap];       // multi-event steps: the columns at positions hi..hi+31
     alignas(16) int mv_a[kRecCap];  // label moves (column, new position) of a multi-event replay
     alignas(16) int mv_p[kRecCap];
@@ -108,6 +108,8 @@ struct Ctx {
     int *evl, *tmpcol;
     Ctl *ctl;
     BlockExchange *ex;
+    unsigned char *slots;  // DMA variant
+    int slot_bytes;
 };
 
 // What crosses the call boundary of search_path: the matrix pointer, the sizes and the BYTE
@@ -118,6 +120,7 @@ struct Layout {
     const double *C;
     int n, W, Wpad;
     int dist, v, order, pos, pred, y, qdesc, evt, sbits, evb, evl, tmpcol, ctl, ex;
+    int slots, slot_bytes;  // DMA variant: two row slots (direct-to-LDS row requests)
 };
 
 __device__ __forceinline__ Ctx make_ctx(const Layout &l_in)
@@ -152,6 +155,8 @@ __device__ __forceinline__ Ctx make_ctx(const Layout &l_in)
     c.tmpcol = reinterpret_cast<int *>(base + uni(l_in.tmpcol));
     c.ctl = reinterpret_cast<Ctl *>(base + uni(l_in.ctl));
     c.ex = reinterpret_cast<BlockExchange *>(base + uni(l_in.ex));
+    c.slots = base + uni(l_in.slots);
+    c.slot_bytes = uni(l_in.slot_bytes);
     return c;
 }
 
@@ -165,7 +170,7 @@ __device__ __forceinline__ void ctl_init(Ctl *c)
     }
     for (int q = 0; q < kRecCap; ++q) c->apub[q] = 0;
     for (int q = 0; q < 4; ++q) c->res[q] = 0;
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < 3; ++q) {
         c->resq[q].j = c->resq[q].i = 0;
         c->resq[q].v = 0.0;
     }
@@ -462,14 +467,57 @@ __device__ __forceinline__ void replay_records(const Ctx &cx, int hi0, int par, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Direct-to-LDS row request (LDS-DMA, global_load_lds_dwordx4): every lane names its own 16 source
+// bytes, the 64 x 16 bytes of a wave land contiguously at a wave-uniform LDS address (M0) + lane*16
+// -- no vector register is a destination, so nothing the compiler does with registers can meet a
+// load in flight.  The compiler does not count these loads: completion is waited for by hand with
+// s_waitcnt vmcnt(N), N = the requests issued AFTER the one that must have landed (vmcnt retires in
+// order; extra compiler loads or spills issued in between only make the wait longer, never shorter).
+// M0 is written in the same statement that reads it (cdna_hip_programming.md, section 5.7).
+__device__ __forceinline__ void dma_request16(const double *gsrc_lane, unsigned lds_dst_uniform)
+{
+    unsigned keep;
+    // (readfirstlane: the "s" operand must be in a scalar register whatever the compiler can prove)
+    lds_dst_uniform = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst_uniform);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc_lane), "s"(lds_dst_uniform)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void dma_wait()
+{
+    static_assert(N >= 0 && N <= 8, "add the count");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+// LDS byte address of a pointer into the workgroup's LDS block
+__device__ __forceinline__ unsigned lds_address(const void *p)
+{
+    typedef __attribute__((address_space(3))) const unsigned char *lds_cptr;
+    return (unsigned)(unsigned long long)(lds_cptr)p;
+}
+
+// ---------------------------------------------------------------------------------------------
 // One shortest augmenting path from row `start` (lapjv.cpp:221-282).  Called by every thread of
 // the workgroup.  Returns the free column reached (and leaves pred[] in LDS for the backtrack,
 // v[] updated for the READY columns), or -1 with ctl->err set.  Ends with a barrier.
 // TB = upper bound of the workgroup size of the calling kernel: the register budget of this
 // function follows from it (1024 threads: 128 VGPRs; 256 threads, one wave per SIMD: 512).
-template <int CH, bool VEC2, int TB>
+// DMA: the rows of the next two SCAN-list entries are requested TWO relax steps ahead, straight
+// into two LDS slots (a CU pulls a 16-KB row from HBM in ~2,500 cycles, more than a step); without
+// it the next row is requested one step ahead into registers.  DMA needs VEC2.
+template <int CH, bool VEC2, int TB, bool DMA>
 __device__ __noinline__ int search_path(Layout layout, int start_in)
 {
+    static_assert(!DMA || VEC2, "the direct-to-LDS row requests move 16 bytes per lane");
     const Ctx cx = make_ctx(layout);
     const int start = uni(start_in);
     const int tid = threadIdx.x;
@@ -571,6 +619,15 @@ __device__ __noinline__ int search_path(Layout layout, int start_in)
     bool nx_valid = false, pf_valid = false;
     int nx_j = 0, nx_i = 0;
     double nx_v = 0.0;
+    // DMA variant: nx2 = the entry at lo+2.  THREE row slots in rotation: slot sx holds / receives
+    // the row of nx, slot sx+1 receives the row of nx2, and slot sx+2 is the one the waves took the
+    // current row from after the previous barrier -- a request never targets a slot that another
+    // wave may still be reading (the head's own entry C[i][j] lies in ANOTHER wave's piece).
+    // x_valid: the row of nx has been requested.  The third slot shares its memory with the
+    // scratch arrays of the tie replay of a minima collection, which drains the requests first.
+    bool nx2_valid = false, x_valid = false;
+    int nx2_j = 0, nx2_i = 0, sx = 0;
+    (void)nx2_j;
     double cn[CH], cn_head = 0.0;
     double c[CH], c_head = 0.0;
 #pragma unroll
@@ -584,6 +641,29 @@ __device__ __noinline__ int search_path(Layout layout, int start_in)
 #pragma unroll
         for (int r = 0; r < CH; ++r) c[r] = cn[r];
         c_head = cn_head;
+    };
+    // DMA variant: request row ri (every lane its 16-byte pieces, or everybody the first 16
+    // bytes of the matrix when !wide) into slot s.  A wave's 64 pieces land contiguously, so the
+    // slot is the row in column order.
+    constexpr int kDmaGroup = CH / 2;  // requests per row and wave
+    auto dma_row = [&](int ri, bool wide, int s) {
+        const double *row = C + (size_t)ri * n;
+        const unsigned sbase = lds_address(cx.slots) + (unsigned)s * (unsigned)cx.slot_bytes + (unsigned)wave * 1024u;
+#pragma unroll
+        for (int r = 0; r < CH; r += 2)
+            dma_request16(row + (wide ? jl[r] : 0), sbase + (unsigned)(r >> 1) * (unsigned)nt * 16u);
+    };
+    // ... and take the row of the new head out of slot s (after the step's barrier: every wave has
+    // waited for its own pieces before it)
+    auto take_slot = [&](int s, int hj) {
+        const unsigned char *sb = cx.slots + (size_t)s * cx.slot_bytes;
+#pragma unroll
+        for (int r = 0; r < CH; r += 2) {
+            const double2 t = *reinterpret_cast<const double2 *>(sb + ((size_t)(r >> 1) * nt + tid) * 16);
+            c[r] = t.x;
+            c[r + 1] = t.y;
+        }
+        c_head = *reinterpret_cast<const double *>(sb + (size_t)hj * 8);
     };
 #ifdef LAPWARM_STAMPS
     long long cst[16];
@@ -725,10 +805,12 @@ __device__ __noinline__ int search_path(Layout layout, int start_in)
                         td[r] = ps[r] >= hi;
                     }
                 }
-                nx_valid = false;
+                nx_valid = nx2_valid = false;
             } else {
                 // ---- ties: exact ordered replay by wave 0
                 CSTAMP_INC(15);
+                // (the replay's scratch arrays share the third row slot: no request may be in flight)
+                if constexpr (DMA) dma_wait<0>();
                 if (eb) {
                     atomicOr(&cx.evt[wordi], eb << shift);
                     if (sb) atomicOr(&cx.sbits[wordi], sb << shift);
@@ -772,14 +854,19 @@ __device__ __noinline__ int search_path(Layout layout, int start_in)
                     }
                 }
                 nx_valid = lo + 1 < hi;
-                if (nx_valid) {
-                    const QDesc q1 = qdesc[lo + 1];
+                nx2_valid = lo + 2 < hi;
+                {
+                    const QDesc q1 = qdesc[(lo + 1 < n) ? lo + 1 : n - 1];
+                    const QDesc q2 = qdesc[(lo + 2 < n) ? lo + 2 : n - 1];
                     nx_j = uni(q1.j);
                     nx_i = uni(q1.i);
                     nx_v = uni(q1.v);
+                    nx2_j = uni(q2.j);
+                    nx2_i = uni(q2.i);
                 }
             }
             pf_valid = false;
+            x_valid = false;
             CSTAMP(tf1);
             CSTAMP_ADD(12, tf1, tfc);
             CSTAMP_ADD(0, tf1, tf0);
@@ -789,15 +876,43 @@ __device__ __noinline__ int search_path(Layout layout, int start_in)
         // c[] / c_head: the current head's row.  Either it was requested during the previous step
         // (pf_valid: it is already in these registers) or it is requested now.  Indices are clamped
         // for addressing (heads come from SCAN-list entries whose writers validated them).
-        if (!pf_valid) {
-            const int ci = (int)umin_u32((unsigned)head_i, (unsigned)(n - 1));
-            const int cj = (int)umin_u32((unsigned)head_j, (unsigned)(n - 1));
-            const double *row = C + (size_t)ci * n;
-            load_row(row, c);
-            c_head = row[cj];
+        if constexpr (!DMA) {
+            if (!pf_valid) {
+                const int ci = (int)umin_u32((unsigned)head_i, (unsigned)(n - 1));
+                const int cj = (int)umin_u32((unsigned)head_j, (unsigned)(n - 1));
+                const double *row = C + (size_t)ci * n;
+                load_row(row, c);
+                c_head = row[cj];
+            }
         }
         const bool pf_next = nx_valid;
-        {
+        if constexpr (DMA) {
+            // rows of nx (unless already requested) and of nx2, straight into the LDS slots; the
+            // second request is issued whatever the path (a single cache line when there is no
+            // nx2), so that the wait before the barrier can always leave kDmaGroup requests in
+            // flight
+#ifndef LAPWARM_DMA_NOISSUE
+            if (nx_valid && !x_valid) dma_row((int)umin_u32((unsigned)nx_i, (unsigned)(n - 1)), true, sx);
+            dma_row(nx2_valid ? (int)umin_u32((unsigned)nx2_i, (unsigned)(n - 1)) : 0, nx2_valid, (sx + 1 == 3) ? 0 : sx + 1);
+#endif
+            x_valid = nx_valid;
+            if (!pf_valid) {
+                // The current head's row was not requested ahead (first step after a minima
+                // collection, or a head that entered the list one step ago): ordinary loads, waited
+                // for INSIDE this branch.  The compiler does not know about the requests above and
+                // waits for all outstanding loads wherever one of its own is pending; on the
+                // prefetched path nothing of its own may be pending, or every step would drain the
+                // direct-to-LDS requests.
+                const int ci = (int)umin_u32((unsigned)head_i, (unsigned)(n - 1));
+                const int cj = (int)umin_u32((unsigned)head_j, (unsigned)(n - 1));
+                const double *row = C + (size_t)ci * n;
+                load_row(row, c);
+                c_head = row[cj];
+#pragma unroll
+                for (int r = 0; r < CH; ++r) pin(c[r]);
+                pin(c_head);
+            }
+        } else {
             // The request for the NEXT head's row is issued unconditionally (the current row again
             // when the SCAN list holds nothing behind the head: cache hits, result unused), with no
             // branch between the two groups of loads: the number of loads issued after the current
@@ -810,6 +925,25 @@ __device__ __noinline__ int search_path(Layout layout, int start_in)
             load_row(rown, cn);
             cn_head = rown[pj];
         }
+#ifdef LAPWARM_DMA_CHECK
+        if constexpr (DMA) {  // diagnostic build: compare the prefetched row with a direct load
+            if (pf_valid) {
+                double t[CH];
+                const double *row = C + (size_t)head_i * n;
+                load_row(row, t);
+                const double th = row[head_j];
+                int bad = 0;
+#pragma unroll
+                for (int r = 0; r < CH; ++r) bad += (inb[r] && t[r] != c[r]) ? 1 : 0;
+                if (bad) atomicAdd((unsigned long long *)&ctl->stamps[0], (unsigned long long)bad);
+                if (th != c_head && tid == 0) ctl->stamps[1] += 1;
+                if (tid == 0) ctl->stamps[2] += 1;
+            } else if (tid == 0) {
+                ctl->stamps[3] += 1;
+            }
+        }
+#endif
+        const bool y_valid_dma = nx2_valid;  // the other slot will hold the row of nx2
         const int par = step_id & 1;
         step_id++;
         n_steps++;
@@ -819,9 +953,11 @@ __device__ __noinline__ int search_path(Layout layout, int start_in)
             break;
         }
         const int seen = par ? seen1 : seen0;
+        if constexpr (!DMA) {
 #pragma unroll
-        for (int r = 0; r < CH; ++r) pin(c[r]);
-        pin(c_head);
+            for (int r = 0; r < CH; ++r) pin(c[r]);
+            pin(c_head);
+        }
         CSTAMP(tr1);
         CSTAMP_ADD(1, tr1, tr0);
         const double h = (c_head - head_v) - level;
@@ -865,6 +1001,8 @@ __device__ __noinline__ int search_path(Layout layout, int start_in)
         }
         CSTAMP(tr2);
         CSTAMP_ADD(2, tr2, tr1);
+        // DMA: this wave's pieces of the row of nx have landed (only the nx2 request stays in flight)
+        if constexpr (DMA) dma_wait<kDmaGroup>();
         __syncthreads();
         CSTAMP(tr3);
         CSTAMP_ADD(3, tr3, tr2);
@@ -873,6 +1011,7 @@ __device__ __noinline__ int search_path(Layout layout, int start_in)
         const int r0p = ctl->rec[par][0].p;
         const QDesc qd1 = qdesc[(lo + 1 < n) ? lo + 1 : n - 1];
         const QDesc qd2 = qdesc[(lo + 2 < n) ? lo + 2 : n - 1];
+        const QDesc qd3 = qdesc[(lo + 3 < n) ? lo + 3 : n - 1];
         const int tot = uni(tot_raw);
         const int dcnt = tot - seen;  // events + 0x10000 * free events of this step
         if (par)
@@ -908,8 +1047,22 @@ __device__ __noinline__ int search_path(Layout layout, int start_in)
             } else {
                 nx_valid = false;
             }
-            pf_valid = pf_next;
-            take_next_row();
+            if constexpr (DMA) {
+                nx2_valid = lo + 2 < hi;
+                nx2_j = uni(qd3.j);
+                nx2_i = uni(qd3.i);
+                // slot sx holds the row of what is now the head (if it had been requested)
+                pf_valid = x_valid && lo < hi;
+#ifdef LAPWARM_DMA_NOUSE
+                pf_valid = false;
+#endif
+                if (pf_valid) take_slot(sx, head_j);
+                sx = (sx + 1 == 3) ? 0 : sx + 1;
+                x_valid = y_valid_dma;
+            } else {
+                pf_valid = pf_next;
+                take_next_row();
+            }
 #ifdef LAPWARM_STAMPS
             CSTAMP(tr4);
             CSTAMP_ADD(4, tr4, tr3);
@@ -960,7 +1113,8 @@ __device__ __noinline__ int search_path(Layout layout, int start_in)
                     replay_scan_bitmap(cx, hi, lane);
                 // outcome block: one LDS round trip for the other waves
                 const int k1 = (lo + 1 < n) ? lo + 1 : n - 1, k2 = (lo + 2 < n) ? lo + 2 : n - 1;
-                const QDesc e1 = qdesc[k1], e2 = qdesc[k2];
+                const int k3 = (lo + 3 < n) ? lo + 3 : n - 1;
+                const QDesc e1 = qdesc[k1], e2 = qdesc[k2], e3 = qdesc[k3];
                 const int rh = ctl->hi, rt = ctl->target, rm = ctl->nmoves, re = ctl->err;
                 if (lane == 0) {
                     ctl->res[0] = rh;
@@ -969,11 +1123,12 @@ __device__ __noinline__ int search_path(Layout layout, int start_in)
                     ctl->res[3] = re;
                     ctl->resq[0] = e1;
                     ctl->resq[1] = e2;
+                    ctl->resq[2] = e3;
                 }
             }
             __syncthreads();
             const int4 res = *reinterpret_cast<const int4 *>(ctl->res);
-            const QDesc q1 = ctl->resq[0], q2 = ctl->resq[1];
+            const QDesc q1 = ctl->resq[0], q2 = ctl->resq[1], q3 = ctl->resq[2];
             const int hi_new = uni(res.x);
             target = uni(res.y);
             if (target >= 0) break;
@@ -1001,8 +1156,21 @@ __device__ __noinline__ int search_path(Layout layout, int start_in)
             nx_j = uni(q2.j);
             nx_i = uni(q2.i);
             nx_v = uni(q2.v);
-            pf_valid = pf_next;
-            take_next_row();
+            if constexpr (DMA) {
+                nx2_valid = lo + 2 < hi;
+                nx2_j = uni(q3.j);
+                nx2_i = uni(q3.i);
+                pf_valid = x_valid;
+#ifdef LAPWARM_DMA_NOUSE
+                pf_valid = false;
+#endif
+                if (pf_valid) take_slot(sx, head_j);
+                sx = (sx + 1 == 3) ? 0 : sx + 1;
+                x_valid = y_valid_dma;
+            } else {
+                pf_valid = pf_next;
+                take_next_row();
+            }
             CSTAMP(tr4);
             CSTAMP_ADD(4, tr4, tr3);
             CSTAMP_INC(7);

@@ -102,7 +102,12 @@ template <int CH, int LDSL, int TB>
 struct Solver {
     static constexpr bool LDS_STATE = LDSL > 0;
     static constexpr bool COLS = LDSL >= 3;   // column-owned search (labels never move between threads)
-    static constexpr bool VEC2 = LDSL == 4;   // ... with column pairs per thread (16-byte row loads; n even)
+    static constexpr bool VEC2 = LDSL >= 4;   // ... with column pairs per thread (16-byte row loads; n even)
+#ifdef LAPWARM_L5_NODMA  // diagnostic: level-5 storage with the register prefetch of level 4
+    static constexpr bool DMA = false;
+#else
+    static constexpr bool DMA = LDSL == 5;    // ... and direct-to-LDS row requests two steps ahead (x, free list in global memory)
+#endif
     static constexpr int kCacheLimit = (TB <= 256) ? 16 : 4;   // positions per thread whose duals fit in registers
     static constexpr int kCacheLimitY = (TB <= 256) ? 16 : 2;
     // problem
@@ -828,7 +833,7 @@ struct Solver {
             int target;
             if constexpr (COLS) {
                 // ends with a barrier (pred[] is dumped at the end)
-                target = uni(cols::search_path<CH, VEC2, TB>(clay, start));
+                target = uni(cols::search_path<CH, VEC2, TB, DMA>(clay, start));
                 if (target < 0) {
                     err = uni(cctl->err);
                     if (!err) err = 2;
@@ -1213,6 +1218,17 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
 
     Solver<CH, LDSL, TB> s;
     unsigned char *cur = smem;
+    if constexpr (LDSL == 5) {
+        // the three row slots of the direct-to-LDS requests come first; the third one doubles as
+        // the scratch arrays of the tie replay (evl, tmpcol: 8n + 8 bytes)
+        const int slot_bytes = (int)blockDim.x * CH * (int)sizeof(double);
+        s.clay.slots = 0;
+        s.clay.slot_bytes = slot_bytes;
+        cur += 3 * (size_t)slot_bytes + 16;
+    } else {
+        s.clay.slots = 0;
+        s.clay.slot_bytes = 0;
+    }
     BlockExchange *ex = reinterpret_cast<BlockExchange *>(cur);
     cur += sizeof(BlockExchange);
     s.ctrl = reinterpret_cast<Ctrl *>(cur);
@@ -1226,7 +1242,11 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
     s.evb = reinterpret_cast<uint32_t *>(cur);
     cur += sizeof(uint32_t) * Wpad * 2;
     s.Wpad = Wpad;
-    if constexpr (LDSL > 0) {
+    if constexpr (LDSL == 5) {
+        const size_t slot_bytes = (size_t)blockDim.x * CH * sizeof(double);
+        s.evl = reinterpret_cast<int *>(smem + 2 * slot_bytes);
+        s.tmpcol = s.evl + n;
+    } else if constexpr (LDSL > 0) {
         s.evl = reinterpret_cast<int *>(cur);
         cur += sizeof(int) * n;
         s.tmpcol = reinterpret_cast<int *>(cur);
@@ -1257,7 +1277,7 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         cur += sizeof(int) * n;
         s.y = reinterpret_cast<int *>(cur);
         cur += sizeof(int) * n;
-        if constexpr (LDSL > 1) {
+        if constexpr (LDSL > 1 && LDSL != 5) {
             s.x = reinterpret_cast<int *>(cur);
             cur += sizeof(int) * n;
             s.fr = reinterpret_cast<int *>(cur);
@@ -1434,10 +1454,13 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
             st[14] = (long long)(t_serial - t_start);  // greedy + micro-ARR part (SSP branch)
             st[15] = 0;
             for (int q = 16; q < kStatsPerInstance; ++q) st[q] = 0;
-#ifdef LAPWARM_STAMPS
+#if defined(LAPWARM_STAMPS) || defined(LAPWARM_DMA_CHECK)
             if constexpr (LDSL >= 3) {
                 for (int q = 0; q < 16; ++q) st[16 + q] = s.cctl->stamps[q];
-            } else {
+            }
+#endif
+#ifdef LAPWARM_STAMPS
+            if constexpr (LDSL < 3) {
                 for (int q = 0; q < 16; ++q) st[16 + q] = s.stamps[q];
             }
 #endif
@@ -1471,6 +1494,14 @@ size_t solver_lds_bytes(int n, int ch, int level)
     if (level >= 1) bytes += (size_t)n * (2 * sizeof(double) + 5 * sizeof(int)) + 2 * sizeof(int);
     if (level >= 2) bytes += (size_t)n * 2 * sizeof(int);
     if (level >= 3) bytes += sizeof(cols::Ctl) + (size_t)n * (sizeof(cols::QDesc) + sizeof(int)) + 32;  // + alignment slack
+    if (level == 5) {
+        // x and the free-row list live in global memory; three row slots of (padded) row length,
+        // the third one shared with evl / tmpcol
+        bytes -= (size_t)n * 2 * sizeof(int);
+        bytes -= (size_t)n * 2 * sizeof(int) + 2 * sizeof(int);
+        const size_t padded = ((size_t)n + (size_t)ch * 64 - 1) / ((size_t)ch * 64) * ((size_t)ch * 64);
+        bytes += 3 * padded * sizeof(double) + 16;
+    }
     return bytes;
 }
 
@@ -1483,10 +1514,23 @@ static bool legacy_search_forced()
     return forced;
 }
 
+static bool dma_search_disabled()
+{
+    static const bool off = [] {
+        const char *e = getenv("LAPWARM_SEARCH");
+        return e && strcmp(e, "nodma") == 0;
+    }();
+    return off;
+}
+
 int solver_lds_level(int n, int ch)
 {
-    if (!legacy_search_forced() && solver_lds_bytes(n, ch, 3) <= kLdsBudgetBytes)
-        return (n % 2 == 0 && ch >= 2) ? 4 : 3;  // 4 = 3 with column pairs (16-byte row loads)
+    if (!legacy_search_forced()) {
+        // 5 = 4 with direct-to-LDS row requests two steps ahead (needs the global workspace for
+        // x and the free-row list); 4 = 3 with column pairs (16-byte row loads)
+        if (n % 2 == 0 && ch >= 2 && !dma_search_disabled() && solver_lds_bytes(n, ch, 5) <= kLdsBudgetBytes) return 5;
+        if (solver_lds_bytes(n, ch, 3) <= kLdsBudgetBytes) return (n % 2 == 0 && ch >= 2) ? 4 : 3;
+    }
     if (solver_lds_bytes(n, ch, 2) <= kLdsBudgetBytes) return 2;
     if (solver_lds_bytes(n, ch, 1) <= kLdsBudgetBytes) return 1;
     return 0;
@@ -1524,17 +1568,19 @@ hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t st
     solver_geometry(p.n, threads_hint, &threads, &ch);
     if ((long long)threads * ch < p.n) return hipErrorInvalidValue;  // n > 16384
     const int level = solver_lds_level(p.n, ch);
-    if (level < 2 && !p.g_dist) return hipErrorInvalidValue;
+    if ((level < 2 || level == 5) && !p.g_x) return hipErrorInvalidValue;
     const size_t lds = solver_lds_bytes(p.n, ch, level);
 #define LAPWARM_CASE(CHV)                                                               \
     case CHV:                                                                           \
         if (threads <= 256) {                                                           \
+            if (level == 5) return launch_one<(CHV >= 2 ? CHV : 2), 5, 256>(p, threads, lds, stream); \
             if (level == 4) return launch_one<(CHV >= 2 ? CHV : 2), 4, 256>(p, threads, lds, stream); \
             if (level == 3) return launch_one<CHV, 3, 256>(p, threads, lds, stream);    \
             if (level == 2) return launch_one<CHV, 2, 256>(p, threads, lds, stream);    \
             if (level == 1) return launch_one<CHV, 1, 256>(p, threads, lds, stream);    \
             return launch_one<CHV, 0, 256>(p, threads, lds, stream);                    \
         }                                                                               \
+        if (level == 5) return launch_one<(CHV >= 2 ? CHV : 2), 5, 1024>(p, threads, lds, stream); \
         if (level == 4) return launch_one<(CHV >= 2 ? CHV : 2), 4, 1024>(p, threads, lds, stream); \
         if (level == 3) return launch_one<CHV, 3, 1024>(p, threads, lds, stream);       \
         if (level == 2) return launch_one<CHV, 2, 1024>(p, threads, lds, stream);       \
@@ -1560,7 +1606,9 @@ bool solver_needs_global_state(int n)
     for (int c = 1; c <= 16; c <<= 1) {
         const int l = solver_lds_level(n, c);
         if (l < worst) worst = l;
+        if (l == 5) worst = 1;  // level 5 keeps x and the free-row list in global memory
     }
+    if (worst == 5) worst = 1;
     return worst < 2;  // levels 2, 3 and 4 keep everything in LDS
 }
 
