@@ -9,6 +9,11 @@ Workload = BASELINE.json configs[2] (K3): batch=32 per GPU, n=2048, mixed famili
 fp64 costs already in HBM when the timed region starts.  Weak scaling: every rank owns its
 own batch of 32; value = instances all ranks solved / max-over-ranks wall time.
 
+The steps are software-pipelined over two HIP streams (default; --no-overlap turns it off): the
+dense sweeps + OneGNN of step k+1 run beside the per-instance solver of step k, which holds one
+CU per instance (32 of 256).  Every timed step still enqueues one full set of dense stages and
+one solve; the work inside the timed region is exactly K of each.
+
 Usage:  python bench.py [--gpus N --steps K --warmup W]
         python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
@@ -31,6 +36,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_CUS = 256
 
 
 def serial_elems(stats_row, n):
@@ -53,30 +59,75 @@ def recorded_traffic(kernel_prefix="jv_instance_kernel"):
     return best
 
 
-def cpu_baseline(C_host, sd, sample_idx, u_given=None):
-    """Oracle pipeline (NumPy features + torch-CPU OneGNN + C restatement of lapjv_seeded) on a
-    bounded sample, one thread (the reference's methodology pins 1 thread)."""
+def cpu_pipeline_once(C_b, sd, u_given=None):
+    """Oracle pipeline for one instance (NumPy features + torch-CPU OneGNN + C restatement of
+    lapjv_seeded) -- the checker, used here as the CPU baseline ("port")."""
     from oracle import features_np, jv, one_gnn_ref
+    if u_given is not None:  # K2: features + min-trick + seeded solve with the given u
+        features_np.compute_row_features(C_b)
+        u, v = u_given, features_np.min_trick(C_b, u_given)
+    else:
+        u, v = one_gnn_ref.predict(sd, C_b)
+    return jv.seeded_raw(C_b, u, v)
+
+
+def cpu_baseline(C_host, sd, sample_idx, u_given=None):
+    """One thread (the reference's methodology pins 1 thread, scripts/gnn_benchmark.py:26-31)."""
     torch.set_num_threads(1)
     t0 = time.perf_counter()
-    outs = []
-    for b in sample_idx:
-        if u_given is not None:  # K2: features + min-trick + seeded solve with the given u
-            features_np.compute_row_features(C_host[b])
-            u, v = u_given[b], features_np.min_trick(C_host[b], u_given[b])
-        else:
-            u, v = one_gnn_ref.predict(sd, C_host[b])
-        ret, x, y, st = jv.seeded_raw(C_host[b], u, v)
-        outs.append((ret, x, y, st))
+    outs = [cpu_pipeline_once(C_host[b], sd, None if u_given is None else u_given[b]) for b in sample_idx]
     dt = time.perf_counter() - t0
     return len(sample_idx) / dt, dt, outs
+
+
+def _node_worker(args):
+    """One process of the whole-node CPU leg: regenerates the batch, times its share."""
+    B, n, fams, seed, hidden, layers, idx = args
+    for p in (str(ROOT), str(PKG)):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    import torch as _torch
+    _torch.set_num_threads(1)
+    from gnn import OneGNN
+    from solvers.generators import mixed_instances
+    mats, _ = mixed_instances(B, n, idx, families=fams, seed=seed)  # only this worker's instances
+    _torch.manual_seed(0)
+    sd = {k: v.detach().clone() for k, v in OneGNN(21, hidden=hidden, layers=layers).state_dict().items()}
+    t0 = time.perf_counter()
+    for Cb in mats:
+        cpu_pipeline_once(Cb, sd)
+    return time.perf_counter() - t0, len(idx)
+
+
+def cpu_baseline_node(B, n, fams, seed, hidden, layers, per_proc=2):
+    """Whole-node CPU leg: one single-threaded process per host core, each
+    running the oracle pipeline on `per_proc` instances of the same batch; aggregate
+    instances/s = all instances / slowest process."""
+    import multiprocessing as mp
+    # the cores this process may actually use (a one-GPU share of the host, not every core of it)
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 32))
+    jobs = [(B, n, fams, seed, hidden, layers, [(c * per_proc + q) % B for q in range(per_proc)])
+            for c in range(cores)]
+    ctx = mp.get_context("spawn")
+    t0 = time.perf_counter()
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_node_worker, jobs)
+    wall = time.perf_counter() - t0
+    slowest = max(r[0] for r in res)
+    total = sum(r[1] for r in res)
+    return total / slowest, cores, total, slowest, wall
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--batch", type=int, default=32, help="instances per GPU")
     ap.add_argument("--n", type=int, default=2048)
     ap.add_argument("--hidden", type=int, default=192)
@@ -86,18 +137,33 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32,
                     help="instances of the same batch timed through the CPU oracle pipeline on rank 0 at N=1 "
                          "(0 = skip); 32 x n=2048 is ~10 s of single-core work")
+    ap.add_argument("--no-node-baseline", action="store_true",
+                    help="skip the one-process-per-core CPU leg (rank 0, N=1, K3 only)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="run the stages of a step back to back on one stream (no two-stream pipelining)")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="additionally report (separate key, never `value`) the throughput with this many "
+                         "independent K3 batches in flight on separate streams")
     ap.add_argument("--backend", type=str, default="nccl",
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse the "
                          "multi-rank flow on a single GPU)")
-    ap.add_argument("--config", type=str, default="K3", choices=["K2", "K3", "K4"],
-                    help="K3 (default) is the configuration the metric is quoted on; K2 / K4 are the other "
-                         "single-GPU-sized BASELINE configs (K4 = one GPU's 32-instance slice of batch 256)")
+    ap.add_argument("--config", type=str, default="K3", choices=["K2", "K3", "K4", "K5"],
+                    help="K3 (default) is the configuration the metric is quoted on; K2 / K4 / K5 are the other "
+                         "single-GPU-sized BASELINE configs (K4 = one GPU's 32-instance slice of batch 256; "
+                         "K5 = n=16384 large-n stress, batch 1)")
     args = ap.parse_args()
     if args.config == "K2":    # batch=64 n=512 uniform, optimal-dual seeds instead of the GNN
         args.batch, args.n, args.families = 64, 512, "uniform"
     elif args.config == "K4":  # batch=256 n=4096 over 8 GPUs -> 32 per GPU
         args.batch, args.n, args.families = 32, 4096, "uniform"
         args.cpu_sample = min(args.cpu_sample, 8)  # ~0.7 s per n=4096 instance on one core
+    elif args.config == "K5":  # n=16384, 2 GiB of fp64 costs per instance
+        args.batch, args.n, args.families = 1, 16384, "uniform"
+        args.cpu_sample = min(args.cpu_sample, 1)
+    if args.steps is None:
+        args.steps = 1 if args.config == "K5" else 3
+    if args.warmup is None:
+        args.warmup = 1
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -120,6 +186,7 @@ def main():
             dist.init_process_group(args.backend)
 
     from gnn import OneGNN, WarmStartPipeline
+    from gnn.bench_core import run_sharded
     from lap import _hip
     from solvers.generators import mixed_batch
 
@@ -138,50 +205,41 @@ def main():
     lib = _hip.load()
     lib.lapwarm_profile_enable(1)
 
-    from gnn.sharding import gather_assignments
-
     u_k2 = None
     if args.config == "K2":
         _, u_k2, _, _ = pipe.optimal_duals_batch(C)  # "oracle u": not part of the timed step
+    overlap = (not args.no_overlap) and u_k2 is None
+    solver_ms = []
 
-    def step():
+    def solve_local():
         if u_k2 is not None:
             from gnn.features import min_trick_device, row_features_device
             feat, _ = row_features_device(C)          # K2 times features + col-min + seeded JV
             v = min_trick_device(C, u_k2)
             x, y, ret, stats = pipe.seeded_batch(C, u_k2, v)
-            out = {"x": x, "y": y, "ret": ret, "stats": stats, "u": u_k2, "v": v}
-        else:
-            out = pipe.solve_batch(C)
-        if distributed:
-            # the one exchange step: assignments to rank 0 (RCCL; gloo needs host tensors)
-            xs = out["x"] if args.backend == "nccl" else out["x"].cpu()
-            out["x_all"] = gather_assignments(xs, dst=0)
-        return out
+            return {"x": x, "y": y, "ret": ret, "stats": stats, "u": u_k2, "v": v}
+        if overlap:
+            # solve what was submitted during the previous step; submit this step's dense stages
+            out = pipe.pipeline_step(C_next=C)
+            out["done"].synchronize()  # the gather below (and the caller) read x
+            return out
+        return pipe.solve_batch(C)
 
-    def sync():
-        torch.cuda.synchronize(dev)
-        if distributed:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    out = None
-    for _ in range(args.warmup):
-        out = step()
-    sync()
-    solver_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-        # reading the bracket waits for this step's solver kernel only; the step's remaining work
-        # is the gather, so this does not add idle time inside the timed region
+    def after_step(out):
+        # reading the bracket waits for this step's solver kernel only
         solver_ms.append(lib.lapwarm_profile_last_solver_ms())
-    sync()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def device_sync():
+        torch.cuda.synchronize(dev)
+
+    if overlap:
+        pipe.pipeline_submit(C)  # primes the pipeline (untimed, like the warm-up steps)
+    out, elapsed = run_sharded(solve_local, args.steps, args.warmup, distributed=distributed,
+                               gather_on_host=(args.backend != "nccl"), device_sync=device_sync,
+                               after_step=after_step)
+    if overlap:
+        pipe.pipeline_drain()
+    solver_ms = solver_ms[-args.steps:]
 
     stats = out["stats"].cpu().numpy()
     ret = out["ret"].cpu().numpy()
@@ -193,6 +251,7 @@ def main():
         alg_bytes = 8.0 * E
         achieved = alg_bytes / (solver_avg_ms * 1e-3) / 1e9
         branches = {int(k): int(c) for k, c in zip(*np.unique(stats[:, 0], return_counts=True))}
+        cus_busy = min(B, N_CUS)  # one workgroup = one instance = one CU
         line = {
             "metric": "LAP instances/sec (whole node), n=%d warm-start pipeline" % n,
             "value": round(value, 3),
@@ -216,7 +275,10 @@ def main():
                 "n": n,
                 "parallelism": "batch-sharded x%d, one %s gather of assignments" % (
                     world, "RCCL" if args.backend == "nccl" else args.backend),
+                "stage_overlap": ("two HIP streams: dense sweeps + OneGNN of step k+1 beside the solver of step k"
+                                  if overlap else "none (stages back to back on one stream)"),
                 "solver_threads_hint": args.threads_hint,
+                "solver_search": os.environ.get("LAPWARM_SEARCH", "legacy"),
                 "branches": branches,
                 "ret_nonzero": int((ret != 0).sum()),
             },
@@ -230,8 +292,13 @@ def main():
                 "traffic": recorded_traffic() if args.config == "K3" and (B, n) == (32, 2048) else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(solver_avg_ms, 3),
-                "note": "latency-bound chain of dependent row scans; achieved = 8*E/launch time with E counted "
-                        "by the kernel; traffic = HBM bytes per launch from separate rocprofv3 --pmc passes "
+                "cus_occupied": cus_busy,
+                "cus_total": N_CUS,
+                "per_cu_GBps": round(achieved / cus_busy, 3),
+                "note": "latency-bound chain of dependent row scans on ONE CU per instance (the kernel occupies "
+                        "cus_occupied of cus_total CUs; a CU pulls ~25 GB/s from HBM at best, "
+                        "tools/micro/mlp_bench.hip); achieved = 8*E/launch time with E counted by the kernel; "
+                        "traffic = HBM bytes per launch from separate rocprofv3 --pmc passes "
                         "(profiles/*_pmc_traffic.txt, 2*FETCH_SIZE+WRITE_SIZE)",
             },
         }
@@ -254,11 +321,49 @@ def main():
                 "value": round(cpu_val, 4),
                 "unit": "instances/s",
                 "cores": 1,
+                "host_cores": os.cpu_count(),
+                "usable_cores": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count(),
                 "kind": "port",
-                "sample": "%d of the %d bench instances (%s), oracle pipeline, %.1f s"
+                "what": "this repository's CPU restatement of the reference pipeline (oracle/: NumPy features, "
+                        "torch-CPU OneGNN forward, C restatement of lapjv_seeded verified bit-exact against the "
+                        "reference build) -- the reference itself cannot travel to the GPU box",
+                "sample": "%d of the %d bench instances (%s), oracle pipeline, 1 thread, %.1f s"
                           % (len(idx), B, ",".join(names[b] for b in idx), cpu_dt),
             }
             line["parity_spot_check"] = {"instances": len(idx), "bit_exact": exact}
+            if args.config == "K3" and not args.no_node_baseline:
+                nv, cores, total, slowest, wall = cpu_baseline_node(B, n, fams, 1234 + rank, args.hidden, args.layers)
+                line["cpu_baseline_node"] = {
+                    "value": round(nv, 3),
+                    "unit": "instances/s",
+                    "cores": cores,
+                    "kind": "port",
+                    "sample": "%d single-threaded processes (one per host core) x %d instances of the same batch, "
+                              "oracle pipeline; slowest process %.1f s, wall incl. start-up %.1f s"
+                              % (cores, total // max(1, cores), slowest, wall),
+                }
+        if world == 1 and args.inflight > 1 and u_k2 is None:
+            # several independent batches in flight (a service that keeps the other 224 CUs busy);
+            # clearly NOT the configured one-batch-per-step metric
+            pipes = [WarmStartPipeline(model, dev, threads_hint=args.threads_hint) for _ in range(args.inflight)]
+            streams = [torch.cuda.Stream(dev) for _ in range(args.inflight)]
+            Cs = [C] + [C.clone() for _ in range(args.inflight - 1)]
+            lib.lapwarm_profile_enable(0)
+            for rep in range(2):  # warm-up pass, timed pass
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    for pp, ss, cc in zip(pipes, streams, Cs):
+                        with torch.cuda.stream(ss):
+                            pp.solve_batch(cc, want_stats=False)
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t0
+            line["throughput_batches_in_flight"] = {
+                "batches_in_flight": args.inflight,
+                "value": round(args.inflight * B * args.steps / dt, 3),
+                "unit": "instances/s",
+                "note": "NOT the metric: %d independent K3 batches on separate HIP streams per step" % args.inflight,
+            }
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

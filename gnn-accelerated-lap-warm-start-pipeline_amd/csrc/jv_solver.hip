@@ -517,7 +517,16 @@ struct Solver {
                 STAMP_ADD(12, tfe, tfd);
                 finds++;
                 if (uni(ctrl->tie_find) != find_seq) {
-                    // ---- tie-free: apply the shift locally
+                    // ---- tie-free.  Does the path end here?  Decided first, from values read
+                    // BEFORE the barrier: on a path-ending collection nothing below may touch
+                    // y[] / v[] / order[] -- another wave may already be past the loop.
+                    hi = lo + 1;
+                    level = totv;
+                    head_j = min_col;
+                    head_i = uni(min_row_raw);
+                    target = (head_i < 0) ? head_j : -1;
+                    if (target >= 0) break;
+                    // apply the shift locally
 #pragma unroll
                     for (int r = 0; r < CH; ++r) {
                         if (sb & (1u << r)) {
@@ -532,14 +541,8 @@ struct Solver {
                         }
                     }
                     if (totp != lo && lo >= b0 && lo < b0 + CH) order[lo] = min_col;
-                    hi = lo + 1;
-                    level = totv;
-                    head_j = min_col;
-                    head_i = uni(min_row_raw);
-                    target = (head_i < 0) ? head_j : -1;
                     STAMP_FI(6, tff);
                     STAMP_ADD(13, tff, tfe);
-                    if (target >= 0) break;
                 } else {
                     // ---- ties: exact ordered replay by wave 0 (bitmaps are only built here)
                     if (eb) {
@@ -809,6 +812,10 @@ struct Solver {
         ctrl_seen0 = seen0;
         ctrl_seen1 = seen1;
         ctrl_find_seq = find_seq;
+        // Path exit made safe by construction: every wave has left the search loop (and finished
+        // whatever it still read there) before any wave updates v[] below or thread 0 rewrites
+        // y[] / x[] in the backtrack.  ~25 ns per path (happens-before table).
+        __syncthreads();
         // dual update for the READY columns (lapjv.cpp:270-276): v[j] += d[j] - level
 #pragma unroll
         for (int r = 0; r < CH; ++r) {
@@ -1505,30 +1512,29 @@ size_t solver_lds_bytes(int n, int ch, int level)
     return bytes;
 }
 
-static bool legacy_search_forced()
+// Which shortest-path search runs (LAPWARM_SEARCH): "legacy" (default) = position-owned search of
+// round 1; "cols" = column-owned search (cols_search.hpp), rows requested one step ahead into
+// registers; "dma" = column-owned with direct-to-LDS row requests two steps ahead.  All three are
+// bit-exact; measured on K3 (round 2, profiles/r02_search_variants.txt) the position-owned search
+// is still the fastest, so it stays the default and the other two are kept selectable.
+static int search_mode()
 {
-    static const bool forced = [] {
+    static const int mode = [] {
         const char *e = getenv("LAPWARM_SEARCH");
-        return e && strcmp(e, "legacy") == 0;
+        if (e && strcmp(e, "cols") == 0) return 1;
+        if (e && strcmp(e, "nodma") == 0) return 1;
+        if (e && strcmp(e, "dma") == 0) return 2;
+        return 0;
     }();
-    return forced;
-}
-
-static bool dma_search_disabled()
-{
-    static const bool off = [] {
-        const char *e = getenv("LAPWARM_SEARCH");
-        return e && strcmp(e, "nodma") == 0;
-    }();
-    return off;
+    return mode;
 }
 
 int solver_lds_level(int n, int ch)
 {
-    if (!legacy_search_forced()) {
+    if (search_mode() != 0) {
         // 5 = 4 with direct-to-LDS row requests two steps ahead (needs the global workspace for
         // x and the free-row list); 4 = 3 with column pairs (16-byte row loads)
-        if (n % 2 == 0 && ch >= 2 && !dma_search_disabled() && solver_lds_bytes(n, ch, 5) <= kLdsBudgetBytes) return 5;
+        if (search_mode() == 2 && n % 2 == 0 && ch >= 2 && solver_lds_bytes(n, ch, 5) <= kLdsBudgetBytes) return 5;
         if (solver_lds_bytes(n, ch, 3) <= kLdsBudgetBytes) return (n % 2 == 0 && ch >= 2) ? 4 : 3;
     }
     if (solver_lds_bytes(n, ch, 2) <= kLdsBudgetBytes) return 2;
@@ -1567,7 +1573,9 @@ hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t st
     if (threads_hint <= 0 && p.mode == kModeCold && p.n > 1024 && p.n <= 2048) threads_hint = 512;
     solver_geometry(p.n, threads_hint, &threads, &ch);
     if ((long long)threads * ch < p.n) return hipErrorInvalidValue;  // n > 16384
-    const int level = solver_lds_level(p.n, ch);
+    int level = solver_lds_level(p.n, ch);
+    if (level == 5 && (long long)threads * ch != (((long long)p.n + ch * 64 - 1) / (ch * 64)) * (ch * 64))
+        level = 4;  // the row slots are sized for threads * ch == the padded row length
     if ((level < 2 || level == 5) && !p.g_x) return hipErrorInvalidValue;
     const size_t lds = solver_lds_bytes(p.n, ch, level);
 #define LAPWARM_CASE(CHV)                                                               \

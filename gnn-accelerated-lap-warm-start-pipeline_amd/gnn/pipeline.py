@@ -72,6 +72,8 @@ class WarmStartPipeline:
     def _workspace(self, B, n):
         key = (B, n)
         if key not in self._ws:
+            if len(self._ws) >= 4:  # a handful of shapes at most: drop the oldest
+                self._ws.pop(next(iter(self._ws)))
             nbytes = self.lib.lapwarm_seeded_workspace_bytes(B, n)
             self._ws[key] = (torch.empty((nbytes,), dtype=torch.uint8, device=self.device), nbytes)
         return self._ws[key]
@@ -149,6 +151,56 @@ class WarmStartPipeline:
         u, v = self.predict_batch(C)
         x, y, ret, stats = self.seeded_batch(C, u, v, eps, want_stats)
         return {"x": x, "y": y, "ret": ret, "stats": stats, "u": u, "v": v}
+
+    # ---- two-stream software pipeline: the dense sweeps + OneGNN of batch k+1 run beside the
+    # per-instance solver of batch k.  The solver occupies one CU per instance (32 of the 256 at
+    # K3), the sweeps want the rest; results are identical to solve_batch().
+    def _streams(self):
+        if not hasattr(self, "_s_pred"):
+            self._s_pred = torch.cuda.Stream(self.device)
+            self._s_solve = torch.cuda.Stream(self.device)
+            self._pending = None
+        return self._s_pred, self._s_solve
+
+    @torch.inference_mode()
+    def pipeline_submit(self, C: torch.Tensor):
+        """Enqueue features + OneGNN + min-trick for `C` on the prediction stream."""
+        s_pred, _ = self._streams()
+        s_pred.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s_pred):
+            u, v = self.predict_batch(C)
+            ev = torch.cuda.Event()
+            ev.record(s_pred)
+        self._pending = (C, u, v, ev)
+
+    @torch.inference_mode()
+    def pipeline_step(self, C_next: Optional[torch.Tensor] = None, eps: float = 1e-12,
+                      want_stats: bool = True) -> dict:
+        """Solve the batch submitted last (its duals are ready or being computed on the prediction
+        stream), and submit `C_next` so that its dense stages overlap this solve.  The returned
+        tensors are produced on the solver stream: synchronise (or wait on out["done"]) before
+        reading them."""
+        if self._pending is None:
+            raise RuntimeError("pipeline_submit() first")
+        _, s_solve = self._streams()
+        C, u, v, ev = self._pending
+        self._pending = None
+        s_solve.wait_event(ev)
+        with torch.cuda.stream(s_solve):
+            x, y, ret, stats = self.seeded_batch(C, u, v, eps, want_stats)
+            done = torch.cuda.Event()
+            done.record(s_solve)
+        for t in (C, u, v):
+            t.record_stream(s_solve)
+        if C_next is not None:
+            self.pipeline_submit(C_next)
+        return {"x": x, "y": y, "ret": ret, "stats": stats, "u": u, "v": v, "done": done}
+
+    def pipeline_drain(self):
+        s_pred, s_solve = self._streams()
+        s_pred.synchronize()
+        s_solve.synchronize()
+        self._pending = None
 
 
 class GNNPredictor:

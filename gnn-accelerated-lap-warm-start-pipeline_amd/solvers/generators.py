@@ -145,11 +145,24 @@ def mixed_batch(batch: int, n: int, families=("uniform", "sparse", "metric", "cl
                 seed: int = 1234) -> Tuple[np.ndarray, list]:
     """K3-style batch: `batch` matrices cycling through `families`, per-instance seeds
     drawn from default_rng(seed)."""
-    rng = np.random.default_rng(seed)
-    per = [int(s) for s in rng.integers(0, np.iinfo(np.uint32).max, size=batch)]
-    names = [families[(i * len(families)) // batch] if batch >= len(families)
-             else families[i % len(families)] for i in range(batch)]
+    names, per = _mixed_plan(batch, families, seed)
     out = np.empty((batch, n, n), dtype=np.float64)
     for i, (f, s) in enumerate(zip(names, per)):
         out[i] = generate_family(f, n, s)
     return out, names
+
+
+def _mixed_plan(batch: int, families, seed: int):
+    rng = np.random.default_rng(seed)
+    per = [int(s) for s in rng.integers(0, np.iinfo(np.uint32).max, size=batch)]
+    names = [families[(i * len(families)) // batch] if batch >= len(families)
+             else families[i % len(families)] for i in range(batch)]
+    return names, per
+
+
+def mixed_instances(batch: int, n: int, indices, families=("uniform", "sparse", "metric", "clustered"),
+                    seed: int = 1234):
+    """Only the instances `indices` of mixed_batch(batch, n, families, seed) -- same matrices,
+    without materialising the whole batch (32 MiB each at n = 2048)."""
+    names, per = _mixed_plan(batch, families, seed)
+    return [generate_family(names[i], n, per[i]) for i in indices], [names[i] for i in indices]

@@ -2,6 +2,7 @@
 Python API, against (a) the golden vectors generated from the reference and (b) the CPU oracle
 on the same seeded inputs.  Integer results bit-exact; float32 model outputs within the
 north-star tolerance 1e-5."""
+import os
 import subprocess
 from pathlib import Path
 
@@ -432,6 +433,49 @@ def test_k3_config_full_size(torch_cuda):
             assert stats[b, q] == st[name], (b, fams[b], name, stats[b, q], st[name])
 
 
+def test_two_stream_pipeline_and_graph_capture_match_eager(torch_cuda):
+    """(a) The two-stream software pipeline of bench.py (dense sweeps + OneGNN of batch k+1 beside
+    the solver of batch k) returns exactly what solve_batch returns; (b) the whole per-batch launch
+    chain is capturable in a HIP graph (no allocation, no host sync in the C ABI) and the replayed
+    graph reproduces the eager result."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    from solvers.generators import mixed_batch
+    B, n = 8, 512
+    Cs, _ = mixed_batch(B, n, seed=5)
+    Cs2, _ = mixed_batch(B, n, seed=6)
+    torch.manual_seed(0)
+    model = OneGNN(21, hidden=64, layers=2).eval()
+    pipe = WarmStartPipeline(model, "cuda:0")
+    C1, C2 = torch.from_numpy(Cs).cuda(), torch.from_numpy(Cs2).cuda()
+    ref1, ref2 = pipe.solve_batch(C1), pipe.solve_batch(C2)
+    torch.cuda.synchronize()
+    pipe.pipeline_submit(C1)
+    o1 = pipe.pipeline_step(C_next=C2)
+    o2 = pipe.pipeline_step(C_next=None)
+    pipe.pipeline_drain()
+    for o, r in ((o1, ref1), (o2, ref2)):
+        for key in ("x", "y", "ret", "u", "v"):
+            assert torch.equal(o[key], r[key]), key
+    # HIP graph: warm up on a side stream (workspace + allocator pools), capture, replay twice
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        pipe.solve_batch(C1)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    static_C = C1.clone()
+    with torch.cuda.graph(g):
+        out = pipe.solve_batch(static_C)
+    for src, ref in ((C1, ref1), (C2, ref2)):
+        static_C.copy_(src)
+        g.replay()
+        torch.cuda.synchronize()
+        for key in ("x", "y", "ret", "u", "v"):
+            assert torch.equal(out[key], ref[key]), key
+
+
 @pytest.mark.parametrize("n,hint", [(1024, 1024), (1024, 512), (1024, 256), (2048, 1024), (2048, 512)])
 def test_batched_solver_across_workgroup_geometries(torch_cuda, n, hint):
     """Same inputs through different workgroup geometries (1, 2, 4 or 8 positions per thread:
@@ -458,6 +502,18 @@ def test_batched_solver_across_workgroup_geometries(torch_cuda, n, hint):
             assert np.array_equal(xo, xs[b]) and np.array_equal(yo, ys[b]), (fams[b], rep)
             for q, name in ((4, "paths"), (5, "finds"), (6, "scan_steps"), (7, "scan_elems"), (11, "arr_iters")):
                 assert st[b, q] == so[name], (fams[b], name, st[b, q], so[name])
+
+
+@pytest.mark.parametrize("mode", ["cols", "dma"])
+def test_alternative_search_variants_are_bit_exact(mode):
+    """The column-owned searches of round 2 (LAPWARM_SEARCH=cols: labels in registers, position
+    labels instead of a permutation in LDS; =dma: plus direct-to-LDS row requests two steps ahead)
+    are selectable and bit-exact: native sweep to n = 2048 in a process of its own."""
+    exe = ROOT / "tests" / "native" / "_build" / "parity_driver"
+    env = dict(os.environ, LAPWARM_SEARCH=mode)
+    proc = subprocess.run([str(exe), "2048", "1"], capture_output=True, text=True, timeout=900, env=env)
+    assert proc.returncode == 0, proc.stdout[-3000:]
+    assert "bad=0" in proc.stdout.splitlines()[-1]
 
 
 def test_run_to_run_determinism_under_concurrent_traffic(torch_cuda):

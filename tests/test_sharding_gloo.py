@@ -1,6 +1,8 @@
-"""The N>1 path on CPU: two gloo ranks shard a batch, each solves its slice (with the CPU oracle
-standing in for the per-rank device pipeline) and rank 0 receives every assignment through the
-single gather used by bench.py.  Result must equal the unsharded solve."""
+"""The N>1 path on CPU: two gloo ranks run bench.py's OWN timed loop (gnn/bench_core.run_sharded:
+warm-up + timed steps, the single gather of assignments per step, barrier-bracketed timing, MAX
+over ranks) with the CPU oracle standing in for the per-rank device pipeline.  The code that runs
+under RCCL on the GPU node is the code exercised here; only the solve callable and the backend
+differ.  Result must equal the unsharded solve."""
 import os
 import sys
 from pathlib import Path
@@ -21,19 +23,28 @@ def _worker(rank, world, port, total, n, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from gnn.sharding import gather_assignments, shard_bounds
+    from gnn.bench_core import run_sharded
+    from gnn.sharding import shard_bounds
     from oracle import jv
     from solvers.generators import mixed_batch
     C, _ = mixed_batch(total, n, seed=21)
     lo, hi = shard_bounds(total, world, rank)
-    xs = []
-    for b in range(lo, hi):
-        u = C[b].min(1)
-        v = (C[b] - u[:, None]).min(0)
-        xs.append(jv.seeded_raw(C[b], u, v)[1])
-    x_local = torch.from_numpy(np.stack(xs))
+    calls = []
+
+    def solve_local():  # stands in for WarmStartPipeline.solve_batch on this rank's slice
+        xs = []
+        for b in range(lo, hi):
+            u = C[b].min(1)
+            v = (C[b] - u[:, None]).min(0)
+            xs.append(jv.seeded_raw(C[b], u, v)[1])
+        calls.append(1)
+        return {"x": torch.from_numpy(np.stack(xs))}
+
     sizes = [shard_bounds(total, world, r)[1] - shard_bounds(total, world, r)[0] for r in range(world)]
-    x_all = gather_assignments(x_local, dst=0, sizes=sizes)
+    out, elapsed = run_sharded(solve_local, steps=2, warmup=1, distributed=True, gather_on_host=True, sizes=sizes)
+    assert len(calls) == 3 and elapsed > 0.0
+    x_all = out.get("x_all")
+    assert (x_all is not None) == (rank == 0)
     if rank == 0:
         q.put(x_all.numpy())
     dist.barrier()
