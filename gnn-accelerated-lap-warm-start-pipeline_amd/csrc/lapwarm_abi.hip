@@ -103,13 +103,17 @@ struct Arena {
 };
 Arena g_arena;
 
-// optional event bracket around the per-instance solver kernel (bench.py's roofline leg)
+// optional event bracket around the per-instance solver kernel (bench.py's roofline leg).
+// One bracket per process (the benchmark's single submission thread); guarded by g_prof_mu so
+// that concurrent callers of the batched entry points cannot corrupt it.
+std::mutex g_prof_mu;
 bool g_profile = false;
 hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 bool g_ev_valid = false;
 
 hipError_t profile_begin(hipStream_t s)
 {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (!g_profile) return hipSuccess;
     if (!g_ev0) {
         hipError_t e = hipEventCreate(&g_ev0);
@@ -122,6 +126,7 @@ hipError_t profile_begin(hipStream_t s)
 
 hipError_t profile_end(hipStream_t s)
 {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (!g_profile) return hipSuccess;
     g_ev_valid = true;
     return hipEventRecord(g_ev1, s);
@@ -147,10 +152,15 @@ int lapwarm_device_count(void)
     return c;
 }
 
-void lapwarm_profile_enable(int on) { g_profile = on != 0; }
+void lapwarm_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    g_profile = on != 0;
+}
 
 double lapwarm_profile_last_solver_ms(void)
 {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (!g_ev_valid) return -1.0;
     if (hipEventSynchronize(g_ev1) != hipSuccess) return -1.0;
     float ms = -1.0f;
@@ -436,6 +446,45 @@ int lapwarm_lapjv_dense(const double *C, int n, int *x, int *y)
     void *ws = reinterpret_cast<unsigned char *>(g_arena.ptr) + c.off;
     HIP_TRY(hipMemcpy(dC, C, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
     int rc = lapwarm_lapjv_batched(dC, 1, n, dx, dy, dret, nullptr, ws, ws_bytes, 0, nullptr);
+    if (rc) return rc;
+    int ret = 0;
+    HIP_TRY(hipMemcpy(&ret, dret, sizeof(int), hipMemcpyDeviceToHost));
+    if (ret != 0) return ret;
+    HIP_TRY(hipMemcpy(x, dx, sizeof(int) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(y, dy, sizeof(int) * n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int lapwarm_warmstart_lapjv(const double *C, int n, const double *u, const double *v, int shift_nonneg,
+                            int *x, int *y)
+{
+    if (n <= 0) return -2;
+    if (n > 16384) return -5;
+    std::lock_guard<std::mutex> lock(g_arena.mu);
+    const size_t ws_sweep = lapwarm_sweep_workspace_bytes(1, n);
+    const size_t ws_solve = lapwarm_seeded_workspace_bytes(1, n);
+    const size_t mat = align_up(sizeof(double) * (size_t)n * n);
+    const size_t total = 2 * mat + 3 * align_up(sizeof(double) * n) + 2 * align_up(sizeof(int) * n) + 512 +
+                         ws_sweep + ws_solve;
+    if (g_arena.reserve(total) != hipSuccess) return -1;
+    Carver c{reinterpret_cast<unsigned char *>(g_arena.ptr), 0};
+    double *dC = c.take<double>((size_t)n * n);
+    double *dR = c.take<double>((size_t)n * n);  // the reduced matrix never leaves the device
+    double *du = c.take<double>(n);
+    double *dv = c.take<double>(n);
+    double *dg = c.take<double>(1);
+    int *dx = c.take<int>(n);
+    int *dy = c.take<int>(n);
+    int *dret = c.take<int>(1);
+    void *wsA = reinterpret_cast<unsigned char *>(g_arena.ptr) + c.off;
+    c.off += align_up(ws_sweep);
+    void *wsB = reinterpret_cast<unsigned char *>(g_arena.ptr) + c.off;
+    HIP_TRY(hipMemcpy(dC, C, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(du, u, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dv, v, sizeof(double) * n, hipMemcpyHostToDevice));
+    int rc = lapwarm_reduce_costs_batched(dC, 1, n, du, dv, shift_nonneg, dR, dg, wsA, ws_sweep, nullptr);
+    if (rc) return rc;
+    rc = lapwarm_lapjv_batched(dR, 1, n, dx, dy, dret, nullptr, wsB, ws_solve, 0, nullptr);
     if (rc) return rc;
     int ret = 0;
     HIP_TRY(hipMemcpy(&ret, dret, sizeof(int), hipMemcpyDeviceToHost));

@@ -59,6 +59,12 @@ int lapwarm_project_feasible(const double *C, int n, double *u, double *v, int m
 int lapwarm_reduce_costs(const double *C, int n, const double *u, const double *v, int shift_nonneg,
                          double *out, double *min_out);
 
+/* WarmStartLAPSolver.solve (solvers/warmstart_solver.py:31-63): C' = C - u 1^T - 1 v^T
+ * (minus min(C') when negative and shift_nonneg), then the cold JV on C'.  One host-to-device
+ * copy of C; the reduced matrix is formed and solved on the device; x, y [n] int32 come back. */
+int lapwarm_warmstart_lapjv(const double *C, int n, const double *u, const double *v, int shift_nonneg,
+                            int *x, int *y);
+
 /* ------------------------------------------------------------------------------------------
  * (2) Batched, device pointers, stream-ordered.  `stream` is a hipStream_t (NULL = default).
  *     Every function returns 0 or <= -1000 (HIP error); per-instance codes go to `ret`.

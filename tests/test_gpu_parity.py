@@ -561,6 +561,20 @@ def test_solver_wrappers_and_error_behaviour():
     assert np.array_equal(r2, np.arange(64)) and abs(cost2 - cost) < 1e-9
     r3, c3, cost3 = WarmStartLAPSolver().solve(C, u, v)
     assert abs(cost3 - cost) < 1e-9 and abs(SciPySolver().solve(C)[2] - cost) < 1e-9
+    # device-resident reduce+solve == the oracle's cold JV on the host-formed reduced matrix
+    # (reference solvers/warmstart_solver.py:49-63), bit-exact, with and without the shift
+    for shift in (True, False):
+        for uu, vv in ((u, v), (u + 0.25, v + 0.125)):  # the second pair makes min(C') negative
+            Cp = C - uu[:, None] - vv[None, :]
+            if shift and Cp.min() < 0:
+                Cp = Cp - Cp.min()
+            if not shift and Cp.min() < 0:
+                continue  # negative costs: the cold JV's answer is still defined, but keep to the reference's use
+            want = oracle.lapjv(Cp)
+            got = WarmStartLAPSolver().solve(C, uu, vv, shift_nonneg=shift)
+            assert np.array_equal(got[1], want[1]) and got[2] == float(C[np.arange(64), want[1]].sum())
+    r4, c4, cost4 = WarmStartLAPSolver(use_lap=False).solve(C, u, v)
+    assert abs(cost4 - cost) < 1e-9
     stats = time_solver_rigorous(lambda: SeededLAPSolver().solve(C, u, v), num_warmups=1, num_repeats=3)
     assert stats["success"] and stats["num_samples"] == 3
     with pytest.raises(ValueError, match="u/v sizes must match C"):

@@ -82,6 +82,54 @@ def test_no_gpu_means_loud_failure():
         compute_row_features(C)
 
 
+def test_harness_import_line_resolves_and_out_of_scope_names_raise_on_use():
+    # scripts/gnn_benchmark.py:51, verbatim
+    from gnn import DualGNN, OneGNN, compute_features, compute_row_features, compute_row_features_torch  # noqa: F401
+    with pytest.raises(NotImplementedError, match="DualGNN"):
+        DualGNN(hidden_dim=64)
+    with pytest.raises(NotImplementedError, match="compute_features"):
+        compute_features(np.zeros((2, 2)))
+    # scripts/gnn_benchmark.py:47
+    from solvers import SciPySolver, SeededLAPSolver, LAPSolver, time_solver_rigorous  # noqa: F401
+    from solvers.advanced_dual import project_feasible, reduce_costs, check_dual_feasible  # noqa: F401
+    assert (LAPSolver().name, SeededLAPSolver().name) == ("LAP", "SeededLAP")
+    from solvers import WarmStartLAPSolver
+    w = WarmStartLAPSolver()
+    assert w.name == "WarmStartLAP" and w.use_lap
+    rows, cols, cost = w.solve(np.zeros((0, 0)), np.zeros(0), np.zeros(0))
+    assert rows.size == 0 and cost == 0.0
+
+
+def test_launcher_beats_the_harness_sys_path_insert(tmp_path):
+    """The reference's scripts insert their repository root at sys.path[0] (scripts/gnn_benchmark.py:21-22),
+    which shadows PYTHONPATH.  run_harness.py must still bind `solvers` / `gnn` / `lap` to this package:
+    a stand-in harness with decoy packages of the same names next to it."""
+    root = tmp_path / "refroot"
+    for name in ("gnn", "solvers", "lap"):
+        (root / name).mkdir(parents=True)
+        (root / name / "__init__.py").write_text("DECOY = True\n")
+    (root / "scripts").mkdir()
+    (root / "scripts" / "harness.py").write_text(
+        "import sys, json\n"
+        "from pathlib import Path\n"
+        "project_root = Path(__file__).parent.parent\n"
+        "sys.path.insert(0, str(project_root))\n"
+        "from solvers import SciPySolver, SeededLAPSolver, LAPSolver, time_solver_rigorous\n"
+        "from gnn import DualGNN, OneGNN, compute_features, compute_row_features, compute_row_features_torch\n"
+        "import lap, gnn, solvers\n"
+        "print(json.dumps({'argv': sys.argv[1:], 'files': [m.__file__ for m in (lap, gnn, solvers)],\n"
+        "                  'decoy': [hasattr(m, 'DECOY') for m in (lap, gnn, solvers)]}))\n")
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, str(PKG / "run_harness.py"), str(root / "scripts" / "harness.py"), "--sizes", "64"],
+                       capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["argv"] == ["--sizes", "64"] and rec["decoy"] == [False, False, False]
+    assert all(f.startswith(str(PKG)) for f in rec["files"])
+
+
 def test_argument_errors_precede_device_work():
     import lap
     with pytest.raises(ValueError, match="2-dimensional"):
