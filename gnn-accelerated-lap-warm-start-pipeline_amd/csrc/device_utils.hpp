@@ -130,23 +130,6 @@ __device__ __forceinline__ double wave_max(double v)
     return readlane_f64(v, kWave - 1);
 }
 
-__device__ __forceinline__ void wave_min_pair(double &v, int &i)
-{
-#define LAPWARM_STEP(C, M)                                          \
-    {                                                               \
-        const double ov = dpp_move<C, M>(pos_inf(), v);             \
-        const int oi = dpp_move<C, M>(0x7fffffff, i);               \
-        if (pair_less(ov, oi, v, i)) {                              \
-            v = ov;                                                 \
-            i = oi;                                                 \
-        }                                                           \
-    }
-    LAPWARM_DPP_REDUCE(LAPWARM_STEP)
-#undef LAPWARM_STEP
-    v = readlane_f64(v, kWave - 1);
-    i = __builtin_amdgcn_readlane(i, kWave - 1);
-}
-
 // Two lexicographically smallest (value, index) pairs; "empty" = (+inf, INT_MAX).
 struct Top2 {
     double a1;
@@ -218,20 +201,6 @@ __device__ __forceinline__ Top2 wave_top2(Top2 t)
     r.a2 = readlane_f64(t.a2, kWave - 1);
     r.i2 = __builtin_amdgcn_readlane(t.i2, kWave - 1);
     return r;
-}
-
-// Exclusive prefix-min over the lanes of a wave (lane 0 gets +inf); *total = wave min.
-__device__ __forceinline__ double wave_excl_prefix_min(double x, int lane, double *total)
-{
-    double incl = x;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const double o = __shfl_up(incl, off, kWave);
-        if (lane >= off) incl = dmin(incl, o);
-    }
-    *total = __shfl(incl, kWave - 1, kWave);
-    const double prev = __shfl_up(incl, 1, kWave);
-    return (lane == 0) ? pos_inf() : prev;
 }
 
 template <int CTRL, int ROW_MASK>
@@ -367,11 +336,9 @@ __device__ __forceinline__ Arr2 arr2_reduce_lanes(const Arr2 &t)
     r.i1 = __builtin_amdgcn_readlane(t.i1, l1);
     r.y1 = __builtin_amdgcn_readlane(t.y1, l1);
     const int lane = threadIdx.x & (kWave - 1);
-    const bool win = (lane & last) == l1 && (WIDTH == 64 || lane < 16 || true);
     const double c2 = ((lane & last) == l1) ? t.a2 : t.a1;
     const int c2i = ((lane & last) == l1) ? t.i2 : t.i1;
     const int c2y = ((lane & last) == l1) ? t.y2 : t.y1;
-    (void)win;
     double m2 = c2;
     if constexpr (WIDTH == 64) {
 #define LAPWARM_STEP(C, M) m2 = dmin(m2, dpp_move<C, M>(pos_inf(), m2));
@@ -417,17 +384,6 @@ struct BlockCtx {
         __syncthreads();
         const int w = lane & (kMaxWaves - 1);
         double r = (w < nwaves) ? ex->d[p][w] : pos_inf();
-#define LAPWARM_STEP(C, M) r = dmin(r, dpp_move<C, M>(pos_inf(), r));
-        LAPWARM_DPP_ROW_REDUCE(LAPWARM_STEP)
-#undef LAPWARM_STEP
-        return readlane_f64(r, 15);
-    }
-
-    // exclusive prefix-min over waves of the per-wave totals (after the caller's own barrier)
-    __device__ __forceinline__ double prefix_min_over_waves(const double *slots) const
-    {
-        const int w = lane & (kMaxWaves - 1);
-        double r = (w < wave) ? slots[w] : pos_inf();
 #define LAPWARM_STEP(C, M) r = dmin(r, dpp_move<C, M>(pos_inf(), r));
         LAPWARM_DPP_ROW_REDUCE(LAPWARM_STEP)
 #undef LAPWARM_STEP
@@ -496,30 +452,6 @@ struct BlockCtx {
         return __builtin_amdgcn_readlane(r, 15);
     }
 
-    __device__ __forceinline__ void min_pair(double &v, int &idx)
-    {
-        wave_min_pair(v, idx);
-        const int p = parity;
-        parity ^= 1;
-        if (lane == 0) {
-            ex->d[p][wave] = v;
-            ex->i[p][wave] = idx;
-        }
-        __syncthreads();
-        double r = ex->d[p][0];
-        int ri = ex->i[p][0];
-        for (int w = 1; w < nwaves; ++w) {
-            const double o = ex->d[p][w];
-            const int oi = ex->i[p][w];
-            if (pair_less(o, oi, r, ri)) {
-                r = o;
-                ri = oi;
-            }
-        }
-        v = r;
-        idx = ri;
-    }
-
     // Workgroup-wide Arr2 reduction; *c0 (owned by thread 0) is broadcast alongside.  One barrier.
     __device__ __forceinline__ Arr2 arr2(const Arr2 &t, double *c0)
     {
@@ -550,16 +482,6 @@ struct BlockCtx {
         }
         *c0 = ex->bcast[p];
         return arr2_reduce_lanes<16>(s);
-    }
-
-    // top2() that also broadcasts one double owned by thread 0
-    __device__ __forceinline__ Top2 top2_bcast(Top2 t, double *val)
-    {
-        if (tid == 0) ex->bcast[parity] = *val;
-        const int p = parity;
-        t = top2(t);
-        *val = ex->bcast[p];
-        return t;
     }
 
     __device__ __forceinline__ Top2 top2(Top2 t)

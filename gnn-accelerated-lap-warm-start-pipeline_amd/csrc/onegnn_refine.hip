@@ -42,11 +42,6 @@ refine_aggregate_kernel(const float *topk, const float *u_pre, const float *w1, 
         const float w = (ok && sum > 0.0f) ? e / sum : 0.0f;
         s_val[r][k] = ok ? val : 0.0f;
         s_w[r][k] = w;
-        if (k == 0 && wsum && row < rows) {
-            float tot = 0.0f;
-            // recomputed below from LDS for a fixed order
-            (void)tot;
-        }
     }
     __syncthreads();
     if (wsum && tid < kRowsPerBlock && row0 + tid < rows) {
