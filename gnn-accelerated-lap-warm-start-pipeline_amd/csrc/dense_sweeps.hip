@@ -22,6 +22,9 @@ constexpr int kSweepThreads = 256;
 // Seeded prelude: one workgroup per row.  Fuses four of the reference's five O(n^2) loops:
 // projection-candidate count, verify, row tightening, tight-edge bitmap + count.
 // ------------------------------------------------------------------------------------------
+// EPT > 0: the row (and v) stay in registers between the two passes (n <= EPT * kSweepThreads), so C
+// is read from HBM exactly once; EPT == 0: rows of any length, second pass re-reads (L2).
+template <int EPT>
 __global__ void __launch_bounds__(kSweepThreads) prelude_kernel(PreludeParams p)
 {
     __shared__ BlockExchange ex;
@@ -38,23 +41,52 @@ __global__ void __launch_bounds__(kSweepThreads) prelude_kernel(PreludeParams p)
     const double *vb = p.v + (size_t)b * n;
     const double ui = p.u[(size_t)b * n + i];
     const double eps = p.eps;
+    const bool first = !p.rerun;
 
+    constexpr int R = EPT > 0 ? EPT : 1;
+    double c[R], vv[R];
     double m = pos_inf();
     int counts = 0;  // low 16 bits: projection candidates, high bits: verify failures
-    for (int j = bc.tid; j < n; j += kSweepThreads) {
-        const double c = row[j];
-        const double vj = vb[j];
-        if (!p.rerun && ((ui + vj) - c) > eps) counts += 1;
-        if (((c - ui) - vj) < -eps) counts += 1 << 16;
-        m = dmin(m, c - vj);
+    if constexpr (EPT > 0) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int j = bc.tid + k * kSweepThreads;
+            c[k] = (j < n) ? row[j] : pos_inf();
+            vv[k] = (j < n) ? vb[j] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int j = bc.tid + k * kSweepThreads;
+            if (j < n) {
+                if (first && ((ui + vv[k]) - c[k]) > eps) counts += 1;
+                if (((c[k] - ui) - vv[k]) < -eps) counts += 1 << 16;
+                m = dmin(m, c[k] - vv[k]);
+            }
+        }
+    } else {
+        for (int j = bc.tid; j < n; j += kSweepThreads) {
+            const double cj = row[j];
+            const double vj = vb[j];
+            if (first && ((ui + vj) - cj) > eps) counts += 1;
+            if (((cj - ui) - vj) < -eps) counts += 1 << 16;
+            m = dmin(m, cj - vj);
+        }
     }
     m = bc.min_f64(m);
     counts = bc.sum_i32(counts);
     const double u_new = m;
     const double teps = p.tight_eps;
-    for (int j = bc.tid; j < n; j += kSweepThreads) {
-        const double r = (row[j] - u_new) - vb[j];
-        if (fabs(r) <= teps) atomicOr(&bits[j >> 5], 1u << (j & 31));
+    if constexpr (EPT > 0) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int j = bc.tid + k * kSweepThreads;
+            if (j < n && fabs((c[k] - u_new) - vv[k]) <= teps) atomicOr(&bits[j >> 5], 1u << (j & 31));
+        }
+    } else {
+        for (int j = bc.tid; j < n; j += kSweepThreads) {
+            const double r = (row[j] - u_new) - vb[j];
+            if (fabs(r) <= teps) atomicOr(&bits[j >> 5], 1u << (j & 31));
+        }
     }
     __syncthreads();
     int cnt = 0;
@@ -71,7 +103,7 @@ __global__ void __launch_bounds__(kSweepThreads) prelude_kernel(PreludeParams p)
         p.tight_cnt[o] = cnt;
         const int viol = counts & 0xffff, bad = counts >> 16;
         int f = 0;
-        if (!p.rerun) {
+        if (first) {
             p.viol_cnt[o] = viol;
             if (viol > 0) f |= kFlagHasViolation;
         }
@@ -235,114 +267,372 @@ reduce_costs_kernel(const double *C, int n, const double *u, const double *v, co
 }
 
 // ------------------------------------------------------------------------------------------
-// Row features: one workgroup per row, the row staged (and sorted) in LDS.
+// Row features: one workgroup per row, the row staged in LDS.
+//
+// The reference sorts every row twice (gnn/features.py:190 for the k smallest and the median,
+// :199 for the median absolute deviation).  Only five order statistics of each sorted array are
+// ever read -- the 16 smallest, the two middle elements -- so this kernel SELECTS them exactly
+// instead of sorting: one 256-bucket histogram over a monotone map of the value
+// (bucket = trunc((x - lo) * 255 / (hi - lo))), a workgroup prefix sum to find the bucket that
+// holds each wanted rank, a gather of that bucket's (<= 64) members and a rank-by-counting in one
+// wave.  Buckets that hold more than 64 members (ties, heavily skewed rows) are narrowed by 8-bit
+// radix passes over the IEEE order key, or recognised as all-equal by a min/max reduction.  Every
+// map used is monotone non-decreasing in x, so the selected values are the ones a sort would put
+// at those ranks, bit for bit.
 // ------------------------------------------------------------------------------------------
 constexpr double kFeatEps = 1e-9;  // gnn/features.py:18
+constexpr int kSelList = 64;       // bucket size one wave ranks directly
 
-__global__ void __launch_bounds__(kSweepThreads) row_features_kernel(FeatureParams p, int P)
+struct SelectState {
+    unsigned hist[256];
+    int wtot[2][4];
+    int bin[3], kk[3], cnt[3], base[3], shift[3], lcount[3];
+    unsigned long long prefix[3];
+    int lowcount;
+    double val[3];
+    double list[2][kSelList];    // bucket members of targets 1, 2
+    double comb[16 + kSelList];  // target 0: the (< 16) values below its bucket, then its bucket
+    double top[16];
+};
+// followed in LDS by one byte per element: its first-level bucket
+
+__device__ __forceinline__ unsigned long long order_key(double x)
+{
+    const long long bts = __double_as_longlong(x + 0.0);  // -0.0 -> +0.0
+    return bts < 0 ? ~(unsigned long long)bts : ((unsigned long long)bts | 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ int lin_bucket(double x, double lo, double scale)
+{
+    const double t = (x - lo) * scale;
+    const int bk = (t >= 255.0) ? 255 : (int)t;
+    return (t > 0.0) ? bk : 0;
+}
+
+// exclusive prefix sum of one int per thread over the 256-thread workgroup; one barrier
+__device__ __forceinline__ int block_excl_scan(int c, const BlockCtx &bc, SelectState *st, int &par)
+{
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const int o = __shfl_up(incl, off, kWave);
+        if (bc.lane >= off) incl += o;
+    }
+    const int p = par;
+    par ^= 1;
+    if (bc.lane == kWave - 1) st->wtot[p][bc.wave] = incl;
+    __syncthreads();
+    int add = 0;
+    for (int w = 0; w < bc.wave; ++w) add += st->wtot[p][w];
+    return incl - c + add;
+}
+
+// Exact order statistics rank[0..NT) (ascending ranks) of s[0..n), all values in [lo, hi].
+// TOP: additionally the rank[0]+1 smallest values, ascending, into st->top (rank[0] <= 15).
+// Results in out[]; every thread returns the same values.  Ends with a barrier.
+template <int NT, bool TOP>
+__device__ __forceinline__ void select_ranks(SelectState *st, const double *s, int n, double lo, double hi,
+                                             const int (&rank)[NT], double (&out)[NT], BlockCtx &bc, int &par)
+{
+    const int tid = bc.tid;
+    unsigned char *bucket_of = reinterpret_cast<unsigned char *>(st + 1);
+    const double width = hi - lo;
+    const double scale = (width > 0.0 && width < pos_inf()) ? 255.0 / width : 0.0;
+    st->hist[tid] = 0;
+    if (tid < NT) {
+        st->lcount[tid] = 0;
+        st->shift[tid] = 64;
+        st->prefix[tid] = 0;
+    }
+    if (tid == 0) st->lowcount = 0;
+    __syncthreads();
+#pragma unroll 4
+    for (int j = tid; j < n; j += kSweepThreads) {
+        const int lb = lin_bucket(s[j], lo, scale);
+        bucket_of[j] = (unsigned char)lb;
+        atomicAdd(&st->hist[lb], 1u);
+    }
+    __syncthreads();
+    {
+        const int c = (int)st->hist[tid];
+        const int excl = block_excl_scan(c, bc, st, par);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (excl <= rank[t] && rank[t] < excl + c) {
+                st->bin[t] = tid;
+                st->kk[t] = rank[t] - excl;
+                st->cnt[t] = c;
+                st->base[t] = excl;
+            }
+        }
+    }
+    __syncthreads();
+    bool alleq[NT];
+    double eqval[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        alleq[t] = false;
+        eqval[t] = 0.0;
+        bool first = true;
+        while (st->cnt[t] > kSelList) {  // LDS value, rewritten only between barriers: uniform
+            const int bin = st->bin[t], shift = st->shift[t];
+            const unsigned long long prefix = st->prefix[t];
+            const int kkt = st->kk[t];
+            if (first || shift == 0) {
+                first = false;
+                double mn = pos_inf(), mx = -pos_inf();
+                for (int j = tid; j < n; j += kSweepThreads) {
+                    if (bucket_of[j] != bin) continue;
+                    const double x = s[j];
+                    if (shift == 64 || (order_key(x) >> shift) == prefix) {
+                        mn = dmin(mn, x);
+                        mx = (x > mx) ? x : mx;
+                    }
+                }
+                mn = bc.min_f64(mn);
+                mx = bc.max_f64(mx);
+                if (mn == mx || shift == 0) {
+                    alleq[t] = true;
+                    eqval[t] = mn;
+                    break;
+                }
+            }
+            st->hist[tid] = 0;
+            __syncthreads();
+            for (int j = tid; j < n; j += kSweepThreads) {
+                if (bucket_of[j] != bin) continue;
+                const unsigned long long key = order_key(s[j]);
+                if (shift == 64 || (key >> shift) == prefix)
+                    atomicAdd(&st->hist[(unsigned)(key >> (shift - 8)) & 255u], 1u);
+            }
+            __syncthreads();
+            const int c = (int)st->hist[tid];
+            const int excl = block_excl_scan(c, bc, st, par);
+            if (excl <= kkt && kkt < excl + c) {
+                st->prefix[t] = (prefix << 8) | (unsigned long long)tid;
+                st->shift[t] = shift - 8;
+                st->kk[t] = kkt - excl;
+                st->cnt[t] = c;
+                st->base[t] += excl;
+            }
+            __syncthreads();
+        }
+    }
+    // gather the members of each target's bucket (and, for TOP, everything below target 0's)
+    {
+        int bin[NT], shift[NT];
+        unsigned long long prefix[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            bin[t] = st->bin[t];
+            shift[t] = st->shift[t];
+            prefix[t] = st->prefix[t];
+        }
+        const int off0 = TOP ? st->base[0] : 0;
+        bool narrowed = false;  // some target went through radix passes: its members need the key
+#pragma unroll
+        for (int t = 0; t < NT; ++t) narrowed = narrowed || shift[t] != 64;
+#pragma unroll 2
+        for (int j = tid; j < n; j += kSweepThreads) {
+            const int lb = bucket_of[j];
+            bool any = false;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) any = any || lb == bin[t];
+            if (!(any || (TOP && lb < bin[0]))) continue;
+            const double x = s[j];
+            const unsigned long long key = narrowed ? order_key(x) : 0ull;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const unsigned long long hi_bits = (shift[t] == 64) ? 0ull : (key >> shift[t]);
+                const bool same = lb == bin[t] && (shift[t] == 64 || hi_bits == prefix[t]);
+                if (same && !alleq[t]) {
+                    const int q = atomicAdd(&st->lcount[t], 1);
+                    if (t == 0)
+                        st->comb[off0 + q] = x;
+                    else
+                        st->list[t - 1][q] = x;
+                }
+                if (TOP && t == 0) {
+                    const bool below = lb < bin[0] || (lb == bin[0] && shift[0] != 64 && hi_bits < prefix[0]);
+                    if (below) st->comb[atomicAdd(&st->lowcount, 1)] = x;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // wave t ranks the bucket of target t by counting; wave 3 orders the smallest values
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (bc.wave == t && !alleq[t]) {
+            const int cnt = st->cnt[t], kkt = st->kk[t];
+            const double *L = (t == 0) ? st->comb + (TOP ? st->base[0] : 0) : st->list[t - 1];
+            const double a = (bc.lane < cnt) ? L[bc.lane] : pos_inf();
+            int r = 0;
+            for (int q = 0; q < cnt; ++q) {
+                const double o = L[q];
+                r += (o < a || (o == a && q < bc.lane)) ? 1 : 0;
+            }
+            if (bc.lane < cnt && r == kkt) st->val[t] = a;
+        }
+    }
+    if (TOP && bc.wave == 3) {
+        const int base0 = st->base[0];
+        const int m = base0 + (alleq[0] ? 0 : st->cnt[0]);
+        const int l0 = bc.lane, l1 = bc.lane + kWave;
+        const double a0 = (l0 < m) ? st->comb[l0] : pos_inf();
+        const double a1 = (l1 < m) ? st->comb[l1] : pos_inf();
+        int r0 = 0, r1 = 0;
+        for (int q = 0; q < m; ++q) {
+            const double o = st->comb[q];
+            r0 += (o < a0 || (o == a0 && q < l0)) ? 1 : 0;
+            r1 += (o < a1 || (o == a1 && q < l1)) ? 1 : 0;
+        }
+        if (l0 < m && r0 <= rank[0]) st->top[r0] = a0;
+        if (l1 < m && r1 <= rank[0]) st->top[r1] = a1;
+        if (alleq[0] && l0 >= base0 && l0 <= rank[0]) st->top[l0] = eqval[0];
+        if (l0 > rank[0] && l0 < 16) st->top[l0] = pos_inf();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) out[t] = alleq[t] ? eqval[t] : st->val[t];
+}
+
+// Three workgroup reductions behind one barrier: min(a), max(b), sum(c) (sum: butterfly inside a
+// wave, then waves in index order -- the same association as BlockCtx::sum_f64).
+__device__ __forceinline__ void reduce_min_max_sum(BlockCtx &bc, double &a, double &b, double &c)
+{
+    a = wave_min(a);
+    b = wave_max(b);
+    c = wave_sum_f64(c);
+    const int p = bc.parity;
+    bc.parity ^= 1;
+    if (bc.lane == 0) {
+        bc.ex->d[p][bc.wave] = a;
+        bc.ex->d[p][kMaxWaves + bc.wave] = b;
+        bc.ex->d[p][2 * kMaxWaves + bc.wave] = c;
+    }
+    __syncthreads();
+    a = bc.ex->d[p][0];
+    b = bc.ex->d[p][kMaxWaves];
+    c = bc.ex->d[p][2 * kMaxWaves];
+    for (int w = 1; w < bc.nwaves; ++w) {
+        a = dmin(a, bc.ex->d[p][w]);
+        const double o = bc.ex->d[p][kMaxWaves + w];
+        b = (o > b) ? o : b;
+        c += bc.ex->d[p][2 * kMaxWaves + w];
+    }
+}
+
+// sum(a), sum(b) (doubles) and sum(k) (int) behind one barrier
+__device__ __forceinline__ void reduce_sum_sum_isum(BlockCtx &bc, double &a, double &b, int &k)
+{
+    a = wave_sum_f64(a);
+    b = wave_sum_f64(b);
+    k = wave_sum_i32(k);
+    const int p = bc.parity;
+    bc.parity ^= 1;
+    if (bc.lane == 0) {
+        bc.ex->d[p][bc.wave] = a;
+        bc.ex->d[p][kMaxWaves + bc.wave] = b;
+        bc.ex->i[p][bc.wave] = k;
+    }
+    __syncthreads();
+    a = bc.ex->d[p][0];
+    b = bc.ex->d[p][kMaxWaves];
+    k = bc.ex->i[p][0];
+    for (int w = 1; w < bc.nwaves; ++w) {
+        a += bc.ex->d[p][w];
+        b += bc.ex->d[p][kMaxWaves + w];
+        k += bc.ex->i[p][w];
+    }
+}
+
+template <bool CACHE_E>
+__global__ void __launch_bounds__(kSweepThreads) row_features_kernel(FeatureParams p, int npad)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     BlockExchange *ex = reinterpret_cast<BlockExchange *>(smem);
     double *s = reinterpret_cast<double *>(smem + sizeof(BlockExchange));
+    double *ev = s + npad;  // exp(-(x - lo)), kept between the two entropy passes when it fits
+    SelectState *st = reinterpret_cast<SelectState *>(s + (CACHE_E ? 2 : 1) * (size_t)npad);
     const int b = blockIdx.y, i = blockIdx.x, n = p.n;
     BlockCtx bc;
     bc.init(ex);
+    int par = 0;
     const double *row = p.C + ((size_t)b * n + i) * n;
     const double *cm = p.colmin + (size_t)b * n;
 
     double lo = pos_inf(), hi = -pos_inf(), sum = 0.0;
-    for (int j = bc.tid; j < P; j += kSweepThreads) {
-        double x = pos_inf();
-        if (j < n) {
-            x = row[j];
-            lo = dmin(lo, x);
-            hi = (x > hi) ? x : hi;
-            sum += x;
-        }
+#pragma unroll 4
+    for (int j = bc.tid; j < n; j += kSweepThreads) {
+        const double x = row[j];
+        lo = dmin(lo, x);
+        hi = (x > hi) ? x : hi;
+        sum += x;
         s[j] = x;
     }
-    lo = bc.min_f64(lo);
-    hi = bc.max_f64(hi);
-    sum = bc.sum_f64(sum);
+    reduce_min_max_sum(bc, lo, hi, sum);
     const double mean = sum / n;
     const double thresh = lo * 1.1;
 
     double sq = 0.0, esum = 0.0;
     int cnts = 0;  // low 16: near-best, high: column-best
+#pragma unroll 4
     for (int j = bc.tid; j < n; j += kSweepThreads) {
         const double x = s[j];
         const double dlt = x - mean;
         sq += dlt * dlt;
-        esum += exp(-(x - lo));
+        const double e = exp(-(x - lo));
+        if constexpr (CACHE_E) ev[j] = e;
+        esum += e;
         if (x <= thresh) cnts += 1;
         if (x == cm[j]) cnts += 1 << 16;
     }
-    sq = bc.sum_f64(sq);
-    esum = bc.sum_f64(esum);
-    cnts = bc.sum_i32(cnts);
+    reduce_sum_sum_isum(bc, sq, esum, cnts);
     const double denom = esum + kFeatEps;
+    const double rdenom = 1.0 / denom;  // p = e * (1/denom): within one ulp of the quotient, far below float32
     double ent = 0.0;
+#pragma unroll 4
     for (int j = bc.tid; j < n; j += kSweepThreads) {
-        const double pj = exp(-(s[j] - lo)) / denom;
+        const double e = CACHE_E ? ev[j] : exp(-(s[j] - lo));
+        const double pj = e * rdenom;
         ent += pj * log(pj + kFeatEps);
     }
     ent = -bc.sum_f64(ent);
 
-    // bitonic sort of the padded row, ascending
-    __syncthreads();
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = bc.tid; t < (P >> 1); t += kSweepThreads) {
-                const int a = 2 * t - (t & (j - 1));
-                const int c = a + j;
-                const double xa = s[a], xc = s[c];
-                const bool asc = (a & k) == 0;
-                if ((xa > xc) == asc) {
-                    s[a] = xc;
-                    s[c] = xa;
-                }
-            }
-            __syncthreads();
-        }
-    }
-    const double med = (n & 1) ? s[n >> 1] : (s[(n >> 1) - 1] + s[n >> 1]) / 2.0;
+    // order statistics of the row: the 16 smallest, the two middle elements
+    const int rk[3] = {(n < 16 ? n : 16) - 1, (n - 1) >> 1, n >> 1};
+    double sel[3];
+    select_ranks<3, true>(st, s, n, lo, hi, rk, sel, bc, par);
+    const double med = (n & 1) ? sel[2] : (sel[1] + sel[2]) / 2.0;
     const int kk = (n < 10) ? n : 10;
     double gap = 0.0, kmean = 0.0, kstd = 0.0;
     if (bc.tid == 0) {
-        if (n >= 2) gap = s[1] - s[0];
+        if (n >= 2) gap = st->top[1] - st->top[0];
         double acc = 0.0;
-        for (int q = 0; q < kk; ++q) acc += s[q];
+        for (int q = 0; q < kk; ++q) acc += st->top[q];
         kmean = acc / kk;
         double a2 = 0.0;
         for (int q = 0; q < kk; ++q) {
-            const double dq = s[q] - kmean;
+            const double dq = st->top[q] - kmean;
             a2 += dq * dq;
         }
         kstd = sqrt(a2 / kk);
         if (p.topk) {
             float *tk = p.topk + ((size_t)b * n + i) * 16;
-            for (int q = 0; q < 16; ++q) tk[q] = (q < n) ? (float)s[q] : __int_as_float(0x7f800000);
+            for (int q = 0; q < 16; ++q) tk[q] = (float)st->top[q];  // +inf beyond n
         }
     }
-    __syncthreads();
-    // |x - median| is non-increasing then non-decreasing along the sorted row (and the +inf
-    // padding keeps it so): one bitonic merge sorts it.
+    // median absolute deviation: the same selection on |x - median|, which lies in [0, dmax]
     for (int j = bc.tid; j < n; j += kSweepThreads) s[j] = fabs(s[j] - med);
+    const double dlo = fabs(lo - med), dhi = fabs(hi - med);
+    const double dmax = (dlo > dhi) ? dlo : dhi;
     __syncthreads();
-    for (int j = P >> 1; j > 0; j >>= 1) {
-        for (int t = bc.tid; t < (P >> 1); t += kSweepThreads) {
-            const int a = 2 * t - (t & (j - 1));
-            const int c = a + j;
-            const double xa = s[a], xc = s[c];
-            if (xa > xc) {
-                s[a] = xc;
-                s[c] = xa;
-            }
-        }
-        __syncthreads();
-    }
+    const int rd[2] = {(n - 1) >> 1, n >> 1};
+    double dsel[2];
+    select_ranks<2, false>(st, s, n, 0.0, dmax, rd, dsel, bc, par);
     if (bc.tid == 0) {
-        double mad = (n & 1) ? s[n >> 1] : (s[(n >> 1) - 1] + s[n >> 1]) / 2.0;
+        double mad = (n & 1) ? dsel[1] : (dsel[0] + dsel[1]) / 2.0;
         if (mad < kFeatEps) mad = kFeatEps;
         double competition = 0.0, difficulty = 0.0;
         if (n >= 2) {
@@ -368,19 +658,18 @@ __global__ void __launch_bounds__(kSweepThreads) row_features_kernel(FeaturePara
     }
 }
 
-int pow2_at_least(int n)
-{
-    int p = 2;
-    while (p < n) p <<= 1;
-    return p;
-}
-
 }  // namespace
 
 hipError_t launch_prelude(const PreludeParams &p, hipStream_t stream)
 {
     if (p.n > 16384) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(prelude_kernel, dim3(p.n, p.batch), dim3(kSweepThreads), 0, stream, p);
+    const dim3 grid(p.n, p.batch), block(kSweepThreads);
+    if (p.n <= 8 * kSweepThreads)
+        hipLaunchKernelGGL(prelude_kernel<8>, grid, block, 0, stream, p);
+    else if (p.n <= 16 * kSweepThreads)
+        hipLaunchKernelGGL(prelude_kernel<16>, grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL(prelude_kernel<0>, grid, block, 0, stream, p);
     return hipGetLastError();
 }
 
@@ -474,12 +763,18 @@ hipError_t launch_reduce_costs(const double *C, int n, int batch, const double *
 hipError_t launch_row_features(const FeatureParams &p, hipStream_t stream)
 {
     if (p.n > 16384 || p.n < 1) return hipErrorInvalidValue;
-    const int P = pow2_at_least(p.n);
-    const size_t lds = sizeof(BlockExchange) + sizeof(double) * (size_t)P;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(row_features_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int npad = (p.n + 1) & ~1;
+    const bool cache = p.n <= 8192;  // two 8-byte arrays, bucket bytes and the selection state within 160 KB of LDS
+    const size_t lds = sizeof(BlockExchange) + sizeof(double) * (size_t)npad * (cache ? 2 : 1) + sizeof(SelectState) +
+                       (size_t)npad;  // + one bucket byte per element
+    const void *fn = cache ? reinterpret_cast<const void *>(row_features_kernel<true>)
+                           : reinterpret_cast<const void *>(row_features_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(row_features_kernel, dim3(p.n, p.batch), dim3(kSweepThreads), lds, stream, p, P);
+    if (cache)
+        hipLaunchKernelGGL(row_features_kernel<true>, dim3(p.n, p.batch), dim3(kSweepThreads), lds, stream, p, npad);
+    else
+        hipLaunchKernelGGL(row_features_kernel<false>, dim3(p.n, p.batch), dim3(kSweepThreads), lds, stream, p, npad);
     return hipGetLastError();
 }
 

@@ -59,6 +59,40 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64 /
+    libhsa-runtime64 and always loads those; if this library had already pulled in the copies
+    under /opt/rocm, the process would hold two runtimes and torch would report no GPU
+    (observed on the MI355X box: `torch.cuda.is_available()` False after a lap.lapjv call).
+    So when a torch installation exists, its libamdhip64 is loaded first -- without importing
+    torch -- and liblapwarm_hip's DT_NEEDED entry (same SONAME) binds to it.
+    LAPWARM_SYSTEM_HIP=1 opts out (processes that never import torch)."""
+    import importlib.util
+    import os
+    import sys
+    if os.environ.get("LAPWARM_SYSTEM_HIP") == "1" or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    bundled = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if bundled.exists():
+        ct.CDLL(str(bundled), mode=ct.RTLD_GLOBAL)
+
+
+def hip_runtimes_in_process():
+    """Paths of the libamdhip64 copies mapped into this process (diagnostics / tests)."""
+    seen = set()
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                seen.add(line.split()[-1])
+    return sorted(seen)
+
+
 def load():
     """Load the shared library (once).  Raises ImportError when it has not been built."""
     global _lib
@@ -68,6 +102,7 @@ def load():
                 f"{LIB_PATH} is missing: build it with `make -C {_PKG_ROOT / 'csrc'}` "
                 "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
                 "There is no CPU fallback for the HIP path.")
+        _share_hip_runtime_with_torch()
         lib = ct.CDLL(str(LIB_PATH))
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here = ABI drift, surface it

@@ -122,6 +122,48 @@ def test_compute_row_features_torch_matches_host_entry(features_cases, torch_cud
     assert tuple(compute_row_features_torch(torch.zeros((0, 0)).cuda()).shape) == (0, 0)
 
 
+def test_row_feature_order_statistics_are_exact_on_adversarial_rows():
+    """The feature kernel selects order statistics (16 smallest, median, MAD) instead of sorting
+    (gnn/features.py:190,199 sort).  Rows built to stress the selection: heavy ties, one huge
+    outlier (every other value in one bucket), all-equal rows, geometric spacing (radix narrowing),
+    -0.0/+0.0, odd and tiny n.  Exact against NumPy's sort-based statistics."""
+    from gnn import compute_row_features
+    from oracle import features_np
+    rs = np.random.RandomState(11)
+
+    def make_row(kind, n):
+        if kind == 0:
+            return rs.uniform(0, 1, n)
+        if kind == 1:
+            return np.round(rs.uniform(0, 1, n) * 4) / 4                          # 5 distinct values
+        if kind == 2:
+            return np.full(n, 0.375)                                              # all equal
+        if kind == 3:
+            return np.where(rs.uniform(size=n) < 0.7, 1e6, rs.uniform(0, 1, n))   # sparse-family shape
+        if kind == 4:
+            r = rs.uniform(0, 1e-3, n)                                            # one huge outlier
+            r[rs.randint(n)] = 1e9
+            return r
+        if kind == 5:
+            return 2.0 ** -rs.randint(0, 900, n).astype(np.float64)               # geometric spacing
+        if kind == 6:
+            return np.where(rs.uniform(size=n) < 0.5, -0.0, 0.0)                  # signed zeros
+        if kind == 7:
+            return -rs.uniform(0, 1, n) * 1e3                                     # negative values
+        return np.sort(rs.uniform(0, 1, n))[::-1].copy()                          # descending
+
+    for n in (1, 2, 3, 15, 16, 17, 63, 64, 65, 200, 257, 1000, 2048):
+        C = np.ascontiguousarray(np.stack([make_row(i % 9, n) for i in range(n)]))
+        got, topk = compute_row_features(C, return_topk=True)
+        want = features_np.row_statistics(C).astype(np.float32)
+        for col in (0, 1, 4, 6, 11, 12):  # min, max, MAD, gap, counting features
+            assert np.array_equal(got[:, col], want[:, col]), (n, col, np.flatnonzero(got[:, col] != want[:, col])[:5])
+        srt = np.sort(C, axis=1)[:, :16].astype(np.float32)
+        assert np.array_equal(topk[:, :min(n, 16)], srt), n
+        assert np.all(np.isposinf(topk[:, min(n, 16):])), n
+        np.testing.assert_allclose(got[:, :13], want, rtol=2e-6, atol=1e-6, err_msg=str(n))
+
+
 def test_row_features_golden(features_cases):
     from gnn import compute_row_features
     z = features_cases
@@ -561,6 +603,7 @@ def test_solver_wrappers_and_error_behaviour():
     assert np.array_equal(r2, np.arange(64)) and abs(cost2 - cost) < 1e-9
     r3, c3, cost3 = WarmStartLAPSolver().solve(C, u, v)
     assert abs(cost3 - cost) < 1e-9 and abs(SciPySolver().solve(C)[2] - cost) < 1e-9
+    from oracle import jv
     # device-resident reduce+solve == the oracle's cold JV on the host-formed reduced matrix
     # (reference solvers/warmstart_solver.py:49-63), bit-exact, with and without the shift
     for shift in (True, False):
@@ -570,7 +613,7 @@ def test_solver_wrappers_and_error_behaviour():
                 Cp = Cp - Cp.min()
             if not shift and Cp.min() < 0:
                 continue  # negative costs: the cold JV's answer is still defined, but keep to the reference's use
-            want = oracle.lapjv(Cp)
+            want = jv.lapjv(Cp)
             got = WarmStartLAPSolver().solve(C, uu, vv, shift_nonneg=shift)
             assert np.array_equal(got[1], want[1]) and got[2] == float(C[np.arange(64), want[1]].sum())
     r4, c4, cost4 = WarmStartLAPSolver(use_lap=False).solve(C, u, v)

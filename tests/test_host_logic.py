@@ -100,6 +100,21 @@ def test_harness_import_line_resolves_and_out_of_scope_names_raise_on_use():
     assert rows.size == 0 and cost == 0.0
 
 
+def test_one_hip_runtime_per_process_library_first_then_torch():
+    """liblapwarm_hip loaded BEFORE torch must not leave two libamdhip64 copies in the process
+    (torch then reports no GPU).  Fresh interpreter: load the library, import torch, count."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from lap import _hip\n"
+            "_hip.load(); a = _hip.hip_runtimes_in_process()\n"
+            "import torch; b = _hip.hip_runtimes_in_process()\n"
+            "print(len(a), len(b), a == b)\n" % str(PKG))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split() == ["1", "1", "True"], r.stdout
+
+
 def test_launcher_beats_the_harness_sys_path_insert(tmp_path):
     """The reference's scripts insert their repository root at sys.path[0] (scripts/gnn_benchmark.py:21-22),
     which shadows PYTHONPATH.  run_harness.py must still bind `solvers` / `gnn` / `lap` to this package:

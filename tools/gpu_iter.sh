@@ -23,6 +23,9 @@ for s in "$@"; do
     bench) step it_bench 400 python bench.py --steps 5 --warmup 2 ;;
     benchq) step it_benchq 300 python bench.py --steps 5 --warmup 2 --cpu-sample 0 ;;
     k2)    step it_k2 300 python bench.py --config K2 --steps 5 --warmup 2 --cpu-sample 0 ;;
+    feat)  step it_feat 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "feature or golden or wrappers or k2_config or k3_config" ;;
+    prof)  cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; step it_prof 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_iter -o r02 -- python bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-node-baseline --no-overlap ;;
+    dense) step it_dense 300 python tools/diag_dense.py uniform && step it_dense_sparse 300 python tools/diag_dense.py sparse && step it_dense_ties 300 python tools/diag_dense.py ties ;;
     pytest) step it_pytest 1100 python -m pytest tests -x -q -m gpu ;;
     smoke) step it_smoke 300 python -c "import __graft_entry__ as g; g.smoke()" ;;
     *) echo "unknown step $s" ;;
