@@ -101,8 +101,12 @@ __device__ __forceinline__ unsigned long long stamp_now()
 template <int CH, int LDSL, int TB>
 struct Solver {
     static constexpr bool LDS_STATE = LDSL > 0;
-    static constexpr bool COLS = LDSL >= 3;   // column-owned search (labels never move between threads)
-    static constexpr bool VEC2 = LDSL >= 4;   // ... with column pairs per thread (16-byte row loads; n even)
+    static constexpr bool COLS = LDSL >= 3 && LDSL <= 5;  // column-owned search (labels never move between threads)
+    static constexpr bool VEC2 = LDSL == 4 || LDSL == 5;  // ... with column pairs per thread (16-byte row loads; n even)
+    // level 6 = level 2 (position-owned search, all state in LDS) + the row of the NEXT queued head
+    // requested one step ahead straight into one of two LDS slots (LDS-DMA); the gathers of a
+    // prefetched step then read LDS instead of HBM
+    static constexpr bool PF = LDSL == 6;
 #ifdef LAPWARM_L5_NODMA  // diagnostic: level-5 storage with the register prefetch of level 4
     static constexpr bool DMA = false;
 #else
@@ -116,8 +120,10 @@ struct Solver {
     // state
     double *dist, *v;
     int *order, *pred, *y, *x, *fr;
-    cols::Layout clay;  // column-owned search (LDSL >= 3): cols_search.hpp
+    cols::Layout clay;  // column-owned search (levels 3-5): cols_search.hpp
     cols::Ctl *cctl;
+    unsigned char *slots;  // level 6: two row slots of slot_bytes each
+    int slot_bytes;
     uint32_t *evt, *sbits, *used;
     uint32_t *evb;  // tie-event bitmap of a relax step, TWO copies selected by the step parity: the
                     // post phase of step t clears bits while pass t+1 may already be setting its own
@@ -405,6 +411,8 @@ struct Solver {
         int seen0 = ctrl_seen0, seen1 = ctrl_seen1;
         int find_seq = ctrl_find_seq;
         int app_pos = -1, app_j = 0, app_i = 0;  // last column appended by a single-event step
+        bool pf_have = false;  // level 6: the current head's row sits in slot pf_slot
+        int pf_slot = 0;
         double level = 0.0;
         int guard = 0;
         while (target < 0) {
@@ -589,15 +597,30 @@ struct Solver {
             }
             const double *row = C + (size_t)head_i * n;
             double c[CH];
+            double c_head;
+            bool from_slot = false;
+            if constexpr (PF) from_slot = pf_have;
+            if (from_slot) {
+                // the row was requested during the previous step and every wave waited for its
+                // pieces before that step's barrier: gather from LDS
+                const double *srow = reinterpret_cast<const double *>(slots + (size_t)pf_slot * slot_bytes);
 #pragma unroll
-            for (int r = 0; r < CH; ++r) {
-                // never form a global address from an out-of-range column: a clamp (one
-                // instruction; the step is instruction-issue bound) rather than a test and branch.
-                // jr[] only ever holds entries of order[], so the clamp is a no-op by construction.
-                const unsigned jc = umin_u32((unsigned)jr[r], (unsigned)(n - 1));
-                c[r] = row[jc];  // unconditional: all gathers in flight
+                for (int r = 0; r < CH; ++r) {
+                    const unsigned jc = umin_u32((unsigned)jr[r], (unsigned)(n - 1));
+                    c[r] = srow[jc];
+                }
+                c_head = srow[head_j];
+            } else {
+#pragma unroll
+                for (int r = 0; r < CH; ++r) {
+                    // never form a global address from an out-of-range column: a clamp (one
+                    // instruction; the step is instruction-issue bound) rather than a test and branch.
+                    // jr[] only ever holds entries of order[], so the clamp is a no-op by construction.
+                    const unsigned jc = umin_u32((unsigned)jr[r], (unsigned)(n - 1));
+                    c[r] = row[jc];  // unconditional: all gathers in flight
+                }
+                c_head = row[head_j];
             }
-            double c_head = row[head_j];
             const int par = step_id & 1;
             // per-step bookkeeping goes here, in the shadow of the gathers, not behind the barrier
             step_id++;
@@ -626,6 +649,29 @@ struct Solver {
                 }
             }
 
+            bool pf_issued = false;
+            int pf_next_slot = 0;
+            if constexpr (PF) {
+                // Request the row of the next queued head into the slot this step does not read.
+                // The other slot's last readers finished before the previous step's barrier.
+                const int ri = uni(nq_i);
+                if (queued && (unsigned)ri < (unsigned)n) {
+                    pf_next_slot = from_slot ? (pf_slot ^ 1) : 0;
+                    const double *nrow = C + (size_t)ri * n;
+                    const unsigned sbase = cols::lds_address(slots) + (unsigned)pf_next_slot * (unsigned)slot_bytes +
+                                           (unsigned)bc.wave * 1024u;
+                    const int nt = (int)blockDim.x;
+#pragma unroll
+                    for (int q = 0; q < CH / 2; ++q) {
+                        // lane's 16 bytes: columns q*2*nt + 2*tid, +1 (clamped into the row; the
+                        // padding beyond n is never read)
+                        int col = q * 2 * nt + 2 * bc.tid;
+                        col = (col < n - 2) ? col : n - 2;
+                        cols::dma_request16(nrow + col, sbase + (unsigned)q * (unsigned)nt * 16u);
+                    }
+                    pf_issued = true;
+                }
+            }
             if (hi >= b0 && hi < b0 + CH && hi < n) {
 #pragma unroll
                 for (int r = 0; r < CH; ++r)
@@ -708,6 +754,13 @@ struct Solver {
             }
             STAMPR(tr2);
             STAMP_ADD(2, tr2, tr1);
+            if constexpr (PF) {
+                // every wave's pieces of the requested row have landed before the barrier releases
+                // the readers of the next step
+                if (pf_issued) cols::dma_wait<0>();
+                pf_have = pf_issued;
+                pf_slot = pf_next_slot;
+            }
             __syncthreads();
             STAMPR(tr3);
             STAMP_ADD(3, tr3, tr2);
@@ -1236,6 +1289,12 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         s.clay.slots = 0;
         s.clay.slot_bytes = 0;
     }
+    s.slots = smem;
+    s.slot_bytes = 0;
+    if constexpr (LDSL == 6) {
+        s.slot_bytes = (int)blockDim.x * CH * (int)sizeof(double);
+        cur += 2 * (size_t)s.slot_bytes + 16;
+    }
     BlockExchange *ex = reinterpret_cast<BlockExchange *>(cur);
     cur += sizeof(BlockExchange);
     s.ctrl = reinterpret_cast<Ctrl *>(cur);
@@ -1262,7 +1321,7 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         s.evl = p.g_evl + (size_t)b * n;
         s.tmpcol = p.g_tmpcol + (size_t)b * (n + 2);
     }
-    if constexpr (LDSL >= 3) {
+    if constexpr (Solver<CH, LDSL, TB>::COLS) {
         cur = smem + ((size_t)(cur - smem) + 15) / 16 * 16;
         s.cctl = reinterpret_cast<cols::Ctl *>(cur);
         s.clay.ctl = (int)(cur - smem);
@@ -1307,7 +1366,7 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
     s.C = p.C + (size_t)b * n * n;
     s.n = n;
     s.W = W;
-    if constexpr (LDSL >= 3) {
+    if constexpr (Solver<CH, LDSL, TB>::COLS) {
         auto off = [&](const void *ptr) { return (int)(reinterpret_cast<const unsigned char *>(ptr) - smem); };
         s.clay.C = s.C;
         s.clay.n = n;
@@ -1349,7 +1408,7 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         return;
     }
 
-    if constexpr (LDSL >= 3) {
+    if constexpr (Solver<CH, LDSL, TB>::COLS) {
         if (tid == 0) cols::ctl_init(s.cctl);
     }
     if (tid == 0) {
@@ -1439,7 +1498,7 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
             st[1] = tight_total;
             st[2] = (branch == kBranchFallback || branch == kBranchCold) ? nf : free_after_greedy;
             st[3] = s.arr_fired;
-            if constexpr (LDSL >= 3) {  // the column-owned search keeps its counters in LDS
+            if constexpr (Solver<CH, LDSL, TB>::COLS) {  // the column-owned search keeps its counters in LDS
                 st[4] = s.cctl->paths;
                 st[5] = s.cctl->finds;
                 st[6] = s.cctl->scan_steps;
@@ -1462,12 +1521,12 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
             st[15] = 0;
             for (int q = 16; q < kStatsPerInstance; ++q) st[q] = 0;
 #if defined(LAPWARM_STAMPS) || defined(LAPWARM_DMA_CHECK)
-            if constexpr (LDSL >= 3) {
+            if constexpr (Solver<CH, LDSL, TB>::COLS) {
                 for (int q = 0; q < 16; ++q) st[16 + q] = s.cctl->stamps[q];
             }
 #endif
 #ifdef LAPWARM_STAMPS
-            if constexpr (LDSL < 3) {
+            if constexpr (!Solver<CH, LDSL, TB>::COLS) {
                 for (int q = 0; q < 16; ++q) st[16 + q] = s.stamps[q];
             }
 #endif
@@ -1500,6 +1559,11 @@ size_t solver_lds_bytes(int n, int ch, int level)
     size_t bytes = sizeof(BlockExchange) + sizeof(Ctrl) + sizeof(uint32_t) * (size_t)Wpad * 5;
     if (level >= 1) bytes += (size_t)n * (2 * sizeof(double) + 5 * sizeof(int)) + 2 * sizeof(int);
     if (level >= 2) bytes += (size_t)n * 2 * sizeof(int);
+    if (level == 6) {
+        // level 2 plus two row slots of the padded row length
+        const size_t padded = ((size_t)n + (size_t)ch * 64 - 1) / ((size_t)ch * 64) * ((size_t)ch * 64);
+        return bytes + 2 * padded * sizeof(double) + 16;
+    }
     if (level >= 3) bytes += sizeof(cols::Ctl) + (size_t)n * (sizeof(cols::QDesc) + sizeof(int)) + 32;  // + alignment slack
     if (level == 5) {
         // x and the free-row list live in global memory; three row slots of (padded) row length,
@@ -1524,6 +1588,7 @@ static int search_mode()
         if (e && strcmp(e, "cols") == 0) return 1;
         if (e && strcmp(e, "nodma") == 0) return 1;
         if (e && strcmp(e, "dma") == 0) return 2;
+        if (e && strcmp(e, "pf") == 0) return 3;
         return 0;
     }();
     return mode;
@@ -1531,7 +1596,9 @@ static int search_mode()
 
 int solver_lds_level(int n, int ch)
 {
-    if (search_mode() != 0) {
+    if (search_mode() == 3) {
+        if (n % 2 == 0 && ch >= 2 && solver_lds_bytes(n, ch, 6) <= kLdsBudgetBytes) return 6;
+    } else if (search_mode() != 0) {
         // 5 = 4 with direct-to-LDS row requests two steps ahead (needs the global workspace for
         // x and the free-row list); 4 = 3 with column pairs (16-byte row loads)
         if (search_mode() == 2 && n % 2 == 0 && ch >= 2 && solver_lds_bytes(n, ch, 5) <= kLdsBudgetBytes) return 5;
@@ -1576,11 +1643,14 @@ hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t st
     int level = solver_lds_level(p.n, ch);
     if (level == 5 && (long long)threads * ch != (((long long)p.n + ch * 64 - 1) / (ch * 64)) * (ch * 64))
         level = 4;  // the row slots are sized for threads * ch == the padded row length
+    if (level == 6 && (long long)threads * ch != (((long long)p.n + ch * 64 - 1) / (ch * 64)) * (ch * 64))
+        level = 2;
     if ((level < 2 || level == 5) && !p.g_x) return hipErrorInvalidValue;
     const size_t lds = solver_lds_bytes(p.n, ch, level);
 #define LAPWARM_CASE(CHV)                                                               \
     case CHV:                                                                           \
         if (threads <= 256) {                                                           \
+            if (level == 6) return launch_one<(CHV >= 2 ? CHV : 2), 6, 256>(p, threads, lds, stream); \
             if (level == 5) return launch_one<(CHV >= 2 ? CHV : 2), 5, 256>(p, threads, lds, stream); \
             if (level == 4) return launch_one<(CHV >= 2 ? CHV : 2), 4, 256>(p, threads, lds, stream); \
             if (level == 3) return launch_one<CHV, 3, 256>(p, threads, lds, stream);    \
@@ -1588,6 +1658,7 @@ hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t st
             if (level == 1) return launch_one<CHV, 1, 256>(p, threads, lds, stream);    \
             return launch_one<CHV, 0, 256>(p, threads, lds, stream);                    \
         }                                                                               \
+        if (level == 6) return launch_one<(CHV >= 2 ? CHV : 2), 6, 1024>(p, threads, lds, stream); \
         if (level == 5) return launch_one<(CHV >= 2 ? CHV : 2), 5, 1024>(p, threads, lds, stream); \
         if (level == 4) return launch_one<(CHV >= 2 ? CHV : 2), 4, 1024>(p, threads, lds, stream); \
         if (level == 3) return launch_one<CHV, 3, 1024>(p, threads, lds, stream);       \

@@ -475,6 +475,34 @@ def test_k3_config_full_size(torch_cuda):
             assert stats[b, q] == st[name], (b, fams[b], name, stats[b, q], st[name])
 
 
+def test_k4_config_slice(torch_cuda):
+    """BASELINE configs[3] (K4: batch 256 over 8 GPUs, n=4096): one GPU's slice shape at a batch
+    the oracle finishes in under a minute (8 of the 32 instances, two per family).  n=4096 runs
+    the solver with x / free-row list in global memory (LDS level 1) and 4 positions per thread.
+    x/y bit-exact and counters equal to the oracle's, fed the GPU's own (u, v)."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    from oracle import jv
+    from solvers.generators import mixed_batch
+    B, n = 8, 4096
+    Cs, fams = mixed_batch(B, n, seed=77)
+    assert sorted(set(fams)) == ["clustered", "metric", "sparse", "uniform"]
+    torch.manual_seed(0)
+    model = OneGNN(21, hidden=192, layers=4).eval()
+    out = WarmStartPipeline(model, "cuda:0").solve_batch(torch.from_numpy(Cs).cuda())
+    torch.cuda.synchronize()
+    u, v = out["u"].cpu().numpy(), out["v"].cpu().numpy()
+    x, y, ret = out["x"].cpu().numpy(), out["y"].cpu().numpy(), out["ret"].cpu().numpy()
+    stats = out["stats"].cpu().numpy()
+    names = ["branch", "tight_edges", "free_rows", "arr_fired", "paths", "finds", "scan_steps", "scan_elems"]
+    for b in range(B):
+        r, xo, yo, st = jv.seeded_raw(Cs[b], u[b].astype(np.float64), v[b])
+        assert r == ret[b] == 0, (b, fams[b], r, ret[b])
+        assert np.array_equal(xo, x[b]) and np.array_equal(yo, y[b]), (b, fams[b])
+        for q, name in enumerate(names):
+            assert stats[b, q] == st[name], (b, fams[b], name, stats[b, q], st[name])
+
+
 def test_two_stream_pipeline_and_graph_capture_match_eager(torch_cuda):
     """(a) The two-stream software pipeline of bench.py (dense sweeps + OneGNN of batch k+1 beside
     the solver of batch k) returns exactly what solve_batch returns; (b) the whole per-batch launch
@@ -546,10 +574,11 @@ def test_batched_solver_across_workgroup_geometries(torch_cuda, n, hint):
                 assert st[b, q] == so[name], (fams[b], name, st[b, q], so[name])
 
 
-@pytest.mark.parametrize("mode", ["cols", "dma"])
+@pytest.mark.parametrize("mode", ["cols", "dma", "pf"])
 def test_alternative_search_variants_are_bit_exact(mode):
     """The column-owned searches of round 2 (LAPWARM_SEARCH=cols: labels in registers, position
     labels instead of a permutation in LDS; =dma: plus direct-to-LDS row requests two steps ahead)
+    and the position-owned search with a one-step-ahead LDS-DMA row request (=pf, LDS level 6)
     are selectable and bit-exact: native sweep to n = 2048 in a process of its own."""
     exe = ROOT / "tests" / "native" / "_build" / "parity_driver"
     env = dict(os.environ, LAPWARM_SEARCH=mode)
