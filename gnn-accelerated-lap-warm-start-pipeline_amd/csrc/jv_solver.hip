@@ -40,19 +40,28 @@
 
 namespace lapwarm {
 
+__host__ __device__ int solver_row_slots(int n, int ch);  // LDS level 8, defined with solver_lds_bytes
+bool large_row_geometry(int n, int *threads, int *ch);
+
 namespace {
 
 struct EventSlot {
     int j, p, i, a;  // event column, its position, its matched row (-1: free), column at order[hi]
 };
 
+constexpr int kRecEvents = 4;  // tie events of one relax step that are resolved without a second barrier
+
 struct alignas(16) Ctrl {
     double level;
-    EventSlot slot[2];
     int hi;
     int target;
+    // records of the first kRecEvents tie events of a step, per step parity, in ARRIVAL order
+    // (slot = returning atomicAdd on ev_total); entry 0 alone describes a single-event step
+    alignas(16) EventSlot rec[2][kRecEvents];
+    // columns at order[hi .. hi+3], published each step by the owners of those positions: what
+    // the events of the step will displace
+    alignas(16) int a_pub[2][kRecEvents];
     int tie_find;     // sequence number of the last minima collection that saw a tie
-    int a_pub[2];     // column at order[hi], published each step by the owner of that position
     int ev_total[2];  // monotonic tie-event counters, one per step parity (readers diff them;
                       // a reader of step t can never see an increment of step t+1)
     int first_fire;
@@ -100,19 +109,24 @@ __device__ __forceinline__ unsigned long long stamp_now()
 
 template <int CH, int LDSL, int TB>
 struct Solver {
-    static constexpr bool LDS_STATE = LDSL > 0;
+    static constexpr bool LDS_STATE = LDSL > 0 && LDSL != 8;
     static constexpr bool COLS = LDSL >= 3 && LDSL <= 5;  // column-owned search (labels never move between threads)
     static constexpr bool VEC2 = LDSL == 4 || LDSL == 5;  // ... with column pairs per thread (16-byte row loads; n even)
     // level 6 = level 2 (position-owned search, all state in LDS) + the row of the NEXT queued head
     // requested one step ahead straight into one of two LDS slots (LDS-DMA); the gathers of a
     // prefetched step then read LDS instead of HBM
-    static constexpr bool PF = LDSL == 6;
+    static constexpr bool PF = LDSL == 6 || LDSL == 8;
+    // level 8 (rows longer than the CU's L1 can hold, n > 4,427): solver state in global memory as
+    // level 0, but EVERY head row is brought into an LDS slot by coalesced LDS-DMA requests and
+    // gathered from there -- the position-owned gather C[i][order[k]] touches a random 128-byte line
+    // per lane, and a 64-128 KiB row thrashes the 32-KiB L1 (each line re-fetched up to CH times)
+    static constexpr bool ROWLDS = LDSL == 8;
 #ifdef LAPWARM_L5_NODMA  // diagnostic: level-5 storage with the register prefetch of level 4
     static constexpr bool DMA = false;
 #else
     static constexpr bool DMA = LDSL == 5;    // ... and direct-to-LDS row requests two steps ahead (x, free list in global memory)
 #endif
-    static constexpr int kCacheLimit = (TB <= 256) ? 16 : 4;   // positions per thread whose duals fit in registers
+    static constexpr int kCacheLimit = (TB <= 256) ? 16 : ((TB <= 512) ? 32 : 4);  // positions per thread whose duals fit in registers
     static constexpr int kCacheLimitY = (TB <= 256) ? 16 : 2;
     // problem
     const double *C;
@@ -122,8 +136,9 @@ struct Solver {
     int *order, *pred, *y, *x, *fr;
     cols::Layout clay;  // column-owned search (levels 3-5): cols_search.hpp
     cols::Ctl *cctl;
-    unsigned char *slots;  // level 6: two row slots of slot_bytes each
+    unsigned char *slots;  // levels 6, 8: row slots of slot_bytes each
     int slot_bytes;
+    int nslots;
     uint32_t *evt, *sbits, *used;
     uint32_t *evb;  // tie-event bitmap of a relax step, TWO copies selected by the step parity: the
                     // post phase of step t clears bits while pass t+1 may already be setting its own
@@ -410,7 +425,11 @@ struct Solver {
         STAMP_ADD(8, tp0, tpath);
         int seen0 = ctrl_seen0, seen1 = ctrl_seen1;
         int find_seq = ctrl_find_seq;
-        int app_pos = -1, app_j = 0, app_i = 0;  // last column appended by a single-event step
+        // columns appended to the SCAN list by the previous step's single-barrier paths (their
+        // owners may still be writing order[]): position app_pos and, after a multi-event step,
+        // app_pos + 1 -- the only two fresh entries the directly following step can look at
+        int app_pos = -1, app_j = 0, app_i = 0, app_j1 = 0, app_i1 = 0;
+        bool app_two = false;
         bool pf_have = false;  // level 6: the current head's row sits in slot pf_slot
         int pf_slot = 0;
         double level = 0.0;
@@ -575,12 +594,14 @@ struct Solver {
                         const int k = b0 + r;
                         if (k >= hi && k < n) {
                             const int j = order[k];
-                            jr[r] = j;
-                            if constexpr (CACHE_V) {
-                                vr[r] = v[j];
-                                if constexpr (CACHE_Y) yr[r] = y[j];
+                            if (j != jr[r]) {  // most positions keep their column
+                                jr[r] = j;
+                                if constexpr (CACHE_V) {
+                                    vr[r] = v[j];
+                                    if constexpr (CACHE_Y) yr[r] = y[j];
+                                }
+                                dk[r] = dist[j];
                             }
-                            dk[r] = dist[j];
                         }
                     }
                 }
@@ -600,10 +621,31 @@ struct Solver {
             double c_head;
             bool from_slot = false;
             if constexpr (PF) from_slot = pf_have;
-            if (from_slot) {
+            if constexpr (ROWLDS) {
+                if (!from_slot) {
+                    // not requested ahead: request it now, wait, and let one barrier publish it
+                    pf_slot = 0;
+                    const unsigned sbase = cols::lds_address(slots) + (unsigned)bc.wave * 1024u;
+                    const int nt = (int)blockDim.x;
+#pragma unroll
+                    for (int q = 0; q < CH / 2; ++q) {
+                        int col = q * 2 * nt + 2 * bc.tid;
+                        col = (col < n - 2) ? col : n - 2;
+                        cols::dma_request16(row + col, sbase + (unsigned)q * (unsigned)nt * 16u);
+                    }
+                    cols::dma_wait<0>();
+                    __syncthreads();
+                    from_slot = true;
+                }
+            }
+            const double *srow = reinterpret_cast<const double *>(slots + (size_t)pf_slot * slot_bytes);
+            if constexpr (ROWLDS) {
+                // the row is in LDS: the compare loop below reads it element by element (no
+                // CH-sized staging array: CH = 8..16 positions per thread would spill it)
+                c_head = srow[head_j];
+            } else if (from_slot) {
                 // the row was requested during the previous step and every wave waited for its
                 // pieces before that step's barrier: gather from LDS
-                const double *srow = reinterpret_cast<const double *>(slots + (size_t)pf_slot * slot_bytes);
 #pragma unroll
                 for (int r = 0; r < CH; ++r) {
                     const unsigned jc = umin_u32((unsigned)jr[r], (unsigned)(n - 1));
@@ -636,9 +678,14 @@ struct Solver {
             const bool queued = (lo + 1 < hi);
             int nq_j = 0, nq_i = 0;
             const int fwd_pos = app_pos;  // only meaningful for the pass that directly follows
+            const bool fwd_two = app_two;
             app_pos = -1;
+            app_two = false;
             if (queued) {
-                if (lo + 1 == fwd_pos) {
+                if (fwd_two && lo == fwd_pos) {
+                    nq_j = app_j1;
+                    nq_i = app_i1;
+                } else if (lo + 1 == fwd_pos) {
                     // appended by the previous step's single-event path: its owner may still be
                     // writing order[app_pos] (no barrier since), so take it from registers
                     nq_j = app_j;
@@ -655,7 +702,7 @@ struct Solver {
                 // Request the row of the next queued head into the slot this step does not read.
                 // The other slot's last readers finished before the previous step's barrier.
                 const int ri = uni(nq_i);
-                if (queued && (unsigned)ri < (unsigned)n) {
+                if (queued && (unsigned)ri < (unsigned)n && nslots > 1) {
                     pf_next_slot = from_slot ? (pf_slot ^ 1) : 0;
                     const double *nrow = C + (size_t)ri * n;
                     const unsigned sbase = cols::lds_address(slots) + (unsigned)pf_next_slot * (unsigned)slot_bytes +
@@ -672,14 +719,22 @@ struct Solver {
                     pf_issued = true;
                 }
             }
-            if (hi >= b0 && hi < b0 + CH && hi < n) {
+            {
+                // owners of positions hi .. hi+3 publish the columns sitting there
+                const unsigned w0 = (unsigned)(b0 - hi);  // window index of our first position
+                if (w0 < (unsigned)kRecEvents || (unsigned)(b0 + CH - 1 - hi) < (unsigned)kRecEvents) {
 #pragma unroll
-                for (int r = 0; r < CH; ++r)
-                    if (b0 + r == hi) ctrl->a_pub[par] = jr[r];
+                    for (int r = 0; r < CH; ++r) {
+                        const unsigned w = (unsigned)(b0 + r - hi);
+                        if (w < (unsigned)kRecEvents && b0 + r < n) ctrl->a_pub[par][w] = jr[r];
+                    }
+                }
             }
             const double v_head = v[head_j];
+            if constexpr (!ROWLDS) {
 #pragma unroll
-            for (int r = 0; r < CH; ++r) pin(c[r]);
+                for (int r = 0; r < CH; ++r) pin(c[r]);
+            }
             pin(c_head);
             STAMPR(tr1);
             STAMP_ADD(1, tr1, tr0);
@@ -697,7 +752,12 @@ struct Solver {
                     vj = vr[r];
                 else
                     vj = v[jr[r]];
-                const double cand = (c[r] - vj) - h;
+                double cr;
+                if constexpr (ROWLDS)
+                    cr = srow[umin_u32((unsigned)jr[r], (unsigned)(n - 1))];
+                else
+                    cr = c[r];
+                const double cand = (cr - vj) - h;
                 const bool imp = act & (cand < dk[r]);
                 const bool ev = imp & (cand == level);
                 dk[r] = imp ? cand : (act ? dk[r] : pos_inf());
@@ -732,25 +792,26 @@ struct Solver {
             }
             const int seen = par ? seen1 : seen0;
             if (my_events) {
-                // no returning atomic and no LDS read on this path: if this turns out to be the
-                // only event of the step the slot is exactly right, otherwise nobody reads it
-                atomicAdd(&ctrl->ev_total[par], my_events);
-                EventSlot sl;
-                sl.j = 0;
-                sl.i = 0;
+                // arrival slot of our first event (the counter is cumulative: `seen` is what it
+                // held when the step began); the first kRecEvents events of a step leave a record
+                int slot_idx = atomicAdd(&ctrl->ev_total[par], my_events) - seen;
 #pragma unroll
                 for (int r = 0; r < CH; ++r) {
-                    if (r == ev_r) {
-                        sl.j = jr[r];
-                        if constexpr (CACHE_Y)
-                            sl.i = yr[r];
-                        else
-                            sl.i = y[jr[r]];
+                    if ((ev_mask >> r) & 1u) {
+                        if (slot_idx < kRecEvents) {
+                            EventSlot sl;
+                            sl.j = jr[r];
+                            if constexpr (CACHE_Y)
+                                sl.i = yr[r];
+                            else
+                                sl.i = y[jr[r]];
+                            sl.p = b0 + r;
+                            sl.a = 0;
+                            ctrl->rec[par][slot_idx] = sl;
+                        }
+                        ++slot_idx;
                     }
                 }
-                sl.p = b0 + ev_r;
-                sl.a = 0;
-                ctrl->slot[par] = sl;
             }
             STAMPR(tr2);
             STAMP_ADD(2, tr2, tr1);
@@ -766,8 +827,8 @@ struct Solver {
             STAMP_ADD(3, tr3, tr2);
             // one LDS round trip for everything the post phase can need
             const int tot_raw = ctrl->ev_total[par];
-            EventSlot sl = ctrl->slot[par];
-            const int a_raw = ctrl->a_pub[par];
+            EventSlot sl = ctrl->rec[par][0];
+            const int a_raw = ctrl->a_pub[par][0];
             const int tot = uni(tot_raw);
             const int cnt = tot - seen;
             if (par)
@@ -832,6 +893,123 @@ struct Solver {
                 }
             } else {
                 STAMP_INC(7);
+                // ---- 2..kRecEvents events (24% of the steps of a uniform instance): still one
+                // barrier.  The serial rule (lapjv.cpp:199-205) takes the events in POSITION order;
+                // event s swaps the column at its position P_s with the one at hi+s.  When no
+                // event sits inside the window [hi, hi+cnt) the swaps are independent: the owner of
+                // P_s moves its column to hi+s and adopts the column published for hi+s.  A free
+                // column among the events ends the path at the first one in position order.
+                bool resolved = false;
+                if (cnt <= kRecEvents) {
+                    // Every lane reads the same records, so the values below are wave-uniform but
+                    // deliberately kept in VECTOR registers: ranking them on the scalar unit is a
+                    // long dependent chain (and spills SGPRs); only the few results that steer
+                    // control flow are moved to scalars.
+                    const EventSlot e1 = ctrl->rec[par][1];
+                    const EventSlot e2 = ctrl->rec[par][2];
+                    const EventSlot e3 = ctrl->rec[par][3];
+                    const int4 aw = *reinterpret_cast<const int4 *>(ctrl->a_pub[par]);
+                    const int fp = ctrl->free_pos[par];
+                    const int kNone = 0x7fffffff;
+                    const int P0 = sl.p, P1 = e1.p, P2 = (cnt > 2) ? e2.p : kNone, P3 = (cnt > 3) ? e3.p : kNone;
+                    int pmin = (P0 < P1) ? P0 : P1;
+                    pmin = (P2 < pmin) ? P2 : pmin;
+                    pmin = (P3 < pmin) ? P3 : pmin;
+                    unsigned bad = ((unsigned)P0 >= (unsigned)n) | ((unsigned)sl.j >= (unsigned)n) | (sl.i >= n) |
+                                   ((unsigned)P1 >= (unsigned)n) | ((unsigned)e1.j >= (unsigned)n) | (e1.i >= n);
+                    if (cnt > 2) bad |= ((unsigned)P2 >= (unsigned)n) | ((unsigned)e2.j >= (unsigned)n) | (e2.i >= n);
+                    if (cnt > 3) bad |= ((unsigned)P3 >= (unsigned)n) | ((unsigned)e3.j >= (unsigned)n) | (e3.i >= n);
+                    bad |= (hi + cnt > n);
+                    if (uni((int)bad)) {
+                        err = 8;
+                        break;
+                    }
+                    if (uni(fp) != kNone) {
+                        // the first free column in position order is the target (its finder recorded
+                        // the position); whatever the earlier swaps would change is never read again
+                        int tj = -1;
+                        tj = (P0 == fp) ? sl.j : tj;
+                        tj = (P1 == fp) ? e1.j : tj;
+                        tj = (P2 == fp) ? e2.j : tj;
+                        tj = (P3 == fp) ? e3.j : tj;
+                        tj = uni(tj);
+                        if (tj >= 0) {
+                            // (free_pos[par] is read by every thread in this phase: it is reset
+                            // behind the barrier at the path end, not here)
+                            // our event bits of this step's bitmap copy must not survive the path
+#pragma unroll
+                            for (int r = 0; r < CH; ++r)
+                                if ((ev_mask >> r) & 1u) atomicAnd(&evb[par * Wpad + ((b0 + r) >> 5)], ~(1u << ((b0 + r) & 31)));
+                            target = tj;
+                            break;
+                        }
+                    } else if (uni(pmin) >= hi + cnt) {
+                        // ranks = position order; entry q goes to SCAN slot hi + rank(q)
+                        const int r0 = (P1 < P0) + (P2 < P0) + (P3 < P0);
+                        const int r1 = (P0 < P1) + (P2 < P1) + (P3 < P1);
+                        const int r2 = (P0 < P2) + (P1 < P2) + (P3 < P2);
+                        const int r3 = (P0 < P3) + (P1 < P3) + (P2 < P3);
+                        int first_j = sl.j, first_i = sl.i, second_j = sl.j, second_i = sl.i;
+                        first_j = (r1 == 0) ? e1.j : first_j, first_i = (r1 == 0) ? e1.i : first_i;
+                        first_j = (r2 == 0) ? e2.j : first_j, first_i = (r2 == 0) ? e2.i : first_i;
+                        first_j = (r3 == 0) ? e3.j : first_j, first_i = (r3 == 0) ? e3.i : first_i;
+                        second_j = (r1 == 1) ? e1.j : second_j, second_i = (r1 == 1) ? e1.i : second_i;
+                        second_j = (r2 == 1) ? e2.j : second_j, second_i = (r2 == 1) ? e2.i : second_i;
+                        second_j = (r3 == 1) ? e3.j : second_j, second_i = (r3 == 1) ? e3.i : second_i;
+                        if (ev_mask) {
+                            // we found one (or more) of these events: our column goes to the SCAN
+                            // list, the column displaced from hi + rank comes to our position
+#pragma unroll
+                            for (int r = 0; r < CH; ++r) {
+                                if ((ev_mask >> r) & 1u) {
+                                    const int pk = b0 + r;
+                                    int rank = r0, jq = sl.j;
+                                    rank = (pk == P1) ? r1 : rank, jq = (pk == P1) ? e1.j : jq;
+                                    rank = (pk == P2) ? r2 : rank, jq = (pk == P2) ? e2.j : jq;
+                                    rank = (pk == P3) ? r3 : rank, jq = (pk == P3) ? e3.j : jq;
+                                    int a = aw.x;
+                                    a = (rank == 1) ? aw.y : a;
+                                    a = (rank == 2) ? aw.z : a;
+                                    a = (rank == 3) ? aw.w : a;
+                                    if ((unsigned)a >= (unsigned)n || (pk != P0 && pk != P1 && pk != P2 && pk != P3)) {
+                                        ctrl->err = 8;  // (read by all threads at the end of the kernel)
+                                    } else {
+                                        jr[r] = a;
+                                        if constexpr (CACHE_V) {
+                                            vr[r] = v[a];
+                                            if constexpr (CACHE_Y) yr[r] = y[a];
+                                        }
+                                        dk[r] = dist[a];
+                                        order[pk] = a;
+                                        order[hi + rank] = jq;
+                                    }
+                                    atomicAnd(&evb[par * Wpad + (pk >> 5)], ~(1u << (pk & 31)));
+                                }
+                            }
+                        }
+                        app_pos = hi;
+                        app_j = uni(first_j);
+                        app_i = uni(first_i);
+                        app_j1 = uni(second_j);
+                        app_i1 = uni(second_i);
+                        app_two = true;
+                        hi += cnt;
+                        ++lo;
+                        if (queued) {
+                            head_j = uni(nq_j);
+                            head_i = uni(nq_i);
+                        } else {
+                            head_j = app_j;
+                            head_i = app_i;
+                        }
+                        resolved = true;
+                    }
+                }
+                if (resolved) {
+                    STAMPR(tr4m);
+                    STAMP_ADD(4, tr4m, tr3);
+                    continue;
+                }
                 if (bc.wave == 0) replay_scan(hi, par);
                 __syncthreads();
                 hi = uni(ctrl->hi);
@@ -845,17 +1023,24 @@ struct Solver {
                     head_j = uni(order[lo]);
                     head_i = uni(y[head_j]);
                 }
+                // The replay swapped every event position with a slot of [old hi, new hi): the only
+                // TODO positions whose column changed are this step's event positions -- and a
+                // thread knows its own (ev_mask).  Rebinding all CH positions here cost four
+                // gathers per position in 23% of the steps: harmless with the state in LDS,
+                // ruinous with the state in global memory (n > 4,427).
+                if (ev_mask) {
 #pragma unroll
-                for (int r = 0; r < CH; ++r) {
-                    const int k = b0 + r;
-                    if (k >= hi && k < n) {
-                        const int j = order[k];
-                        jr[r] = j;
-                        if constexpr (CACHE_V) {
-                            vr[r] = v[j];
-                            if constexpr (CACHE_Y) yr[r] = y[j];
+                    for (int r = 0; r < CH; ++r) {
+                        const int k = b0 + r;
+                        if (((ev_mask >> r) & 1u) && k >= hi && k < n) {
+                            const int j = order[k];
+                            jr[r] = j;
+                            if constexpr (CACHE_V) {
+                                vr[r] = v[j];
+                                if constexpr (CACHE_Y) yr[r] = y[j];
+                            }
+                            dk[r] = dist[j];
                         }
-                        dk[r] = dist[j];
                     }
                 }
             }
@@ -869,6 +1054,10 @@ struct Solver {
         // whatever it still read there) before any wave updates v[] below or thread 0 rewrites
         // y[] / x[] in the backtrack.  ~25 ns per path (happens-before table).
         __syncthreads();
+        if (bc.tid == 0) {
+            ctrl->free_pos[0] = 0x7fffffff;
+            ctrl->free_pos[1] = 0x7fffffff;
+        }
         // dual update for the READY columns (lapjv.cpp:270-276): v[j] += d[j] - level
 #pragma unroll
         for (int r = 0; r < CH; ++r) {
@@ -1291,9 +1480,11 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
     }
     s.slots = smem;
     s.slot_bytes = 0;
-    if constexpr (LDSL == 6) {
+    s.nslots = 0;
+    if constexpr (LDSL == 6 || LDSL == 8) {
         s.slot_bytes = (int)blockDim.x * CH * (int)sizeof(double);
-        cur += 2 * (size_t)s.slot_bytes + 16;
+        s.nslots = (LDSL == 6) ? 2 : solver_row_slots(n, CH);
+        cur += (size_t)s.nslots * (size_t)s.slot_bytes + 16;
     }
     BlockExchange *ex = reinterpret_cast<BlockExchange *>(cur);
     cur += sizeof(BlockExchange);
@@ -1312,7 +1503,7 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         const size_t slot_bytes = (size_t)blockDim.x * CH * sizeof(double);
         s.evl = reinterpret_cast<int *>(smem + 2 * slot_bytes);
         s.tmpcol = s.evl + n;
-    } else if constexpr (LDSL > 0) {
+    } else if constexpr (LDSL > 0 && LDSL != 8) {
         s.evl = reinterpret_cast<int *>(cur);
         cur += sizeof(int) * n;
         s.tmpcol = reinterpret_cast<int *>(cur);
@@ -1332,7 +1523,7 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         cur += sizeof(int) * n;
         cur = smem + ((size_t)(cur - smem) + 15) / 16 * 16;
     }
-    if constexpr (LDSL > 0) {
+    if constexpr (LDSL > 0 && LDSL != 8) {
         s.dist = reinterpret_cast<double *>(cur);
         cur += sizeof(double) * n;
         s.v = reinterpret_cast<double *>(cur);
@@ -1551,12 +1742,37 @@ hipError_t launch_one(const SolverParams &p, int threads, size_t lds_bytes, hipS
 // array in LDS plus pos[] and the SCAN-list entries;
 // 2: position-owned search, every array in LDS; 1: x and the free-row list in global memory;
 // 0: all global
+// row slots of level 8: two (the next queued head's row is requested one step ahead) when they
+// fit beside the control blocks, else one, else none
+__host__ __device__ int solver_row_slots(int n, int ch)
+{
+    const size_t padded = ((size_t)n + (size_t)ch * 64 - 1) / ((size_t)ch * 64) * ((size_t)ch * 64);
+    const size_t W = ((size_t)n + 31) >> 5;
+    const size_t fixed = sizeof(BlockExchange) + sizeof(Ctrl) + sizeof(uint32_t) * ((W + 1) & ~(size_t)1) * 5 + 16;
+    if (fixed + 2 * padded * sizeof(double) <= (size_t)kLdsBudgetBytes) return 2;
+    if (fixed + padded * sizeof(double) <= (size_t)kLdsBudgetBytes) return 1;
+    return 0;
+}
+
+// n = 8192 -> 512 x 16, n = 16384 -> 512 x 32 (exact multiples only: the DMA pieces tile the row)
+bool large_row_geometry(int n, int *threads, int *ch)
+{
+    if (n != 8192 && n != 16384) return false;
+    *threads = 512;
+    *ch = n / 512;
+    return solver_row_slots(n, *ch) >= 1;
+}
+
 size_t solver_lds_bytes(int n, int ch, int level)
 {
     const int W = (n + 31) >> 5;
     const int Wpad = (W + 1) & ~1;
     (void)ch;
     size_t bytes = sizeof(BlockExchange) + sizeof(Ctrl) + sizeof(uint32_t) * (size_t)Wpad * 5;
+    if (level == 8) {  // control blocks + the row slots; all solver state in global memory
+        const size_t padded = ((size_t)n + (size_t)ch * 64 - 1) / ((size_t)ch * 64) * ((size_t)ch * 64);
+        return bytes + (size_t)solver_row_slots(n, ch) * padded * sizeof(double) + 16;
+    }
     if (level >= 1) bytes += (size_t)n * (2 * sizeof(double) + 5 * sizeof(int)) + 2 * sizeof(int);
     if (level >= 2) bytes += (size_t)n * 2 * sizeof(int);
     if (level == 6) {
@@ -1640,12 +1856,24 @@ hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t st
     if (threads_hint <= 0 && p.mode == kModeCold && p.n > 1024 && p.n <= 2048) threads_hint = 512;
     solver_geometry(p.n, threads_hint, &threads, &ch);
     if ((long long)threads * ch < p.n) return hipErrorInvalidValue;  // n > 16384
+    // Rows that no longer fit the L1 (n > 4,427, where the state leaves LDS as well): 512 threads
+    // with n/512 positions each -- duals cached in registers (256 VGPRs per thread at this size),
+    // every head row brought into LDS by coalesced LDS-DMA (level 8).  Seeded mode only: the cold
+    // ARR loop keeps the generic geometry.
+    if (threads_hint <= 0 && p.mode == kModeSeeded && large_row_geometry(p.n, &threads, &ch)) {
+        if (!p.g_x) return hipErrorInvalidValue;
+        const size_t lds8 = solver_lds_bytes(p.n, ch, 8);
+        if (ch == 16) return launch_one<16, 8, 512>(p, threads, lds8, stream);
+        return launch_one<32, 8, 512>(p, threads, lds8, stream);
+    }
     int level = solver_lds_level(p.n, ch);
     if (level == 5 && (long long)threads * ch != (((long long)p.n + ch * 64 - 1) / (ch * 64)) * (ch * 64))
         level = 4;  // the row slots are sized for threads * ch == the padded row length
     if (level == 6 && (long long)threads * ch != (((long long)p.n + ch * 64 - 1) / (ch * 64)) * (ch * 64))
         level = 2;
-    if ((level < 2 || level == 5) && !p.g_x) return hipErrorInvalidValue;
+    if (level == 8 && (long long)threads * ch != (((long long)p.n + ch * 64 - 1) / (ch * 64)) * (ch * 64))
+        level = 0;
+    if ((level < 2 || level == 5 || level == 8) && !p.g_x) return hipErrorInvalidValue;
     const size_t lds = solver_lds_bytes(p.n, ch, level);
 #define LAPWARM_CASE(CHV)                                                               \
     case CHV:                                                                           \
@@ -1678,17 +1906,13 @@ hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t st
 
 bool solver_needs_global_state(int n)
 {
-    int threads, ch;
-    solver_geometry(n, 0, &threads, &ch);
-    int worst = solver_lds_level(n, ch);
-    // a threads_hint may pick another CH: be conservative for every supported geometry
+    // a threads_hint may pick another CH: be conservative for every supported geometry.
+    // Levels 2, 3, 4 and 6 keep everything in LDS; 0, 1, 5 and 8 use the global workspace.
     for (int c = 1; c <= 16; c <<= 1) {
         const int l = solver_lds_level(n, c);
-        if (l < worst) worst = l;
-        if (l == 5) worst = 1;  // level 5 keeps x and the free-row list in global memory
+        if (l < 2 || l == 5 || l == 8) return true;
     }
-    if (worst == 5) worst = 1;
-    return worst < 2;  // levels 2, 3 and 4 keep everything in LDS
+    return false;
 }
 
 }  // namespace lapwarm

@@ -10,11 +10,16 @@ from oracle import jv
 
 torch.manual_seed(0)
 model = OneGNN(21, hidden=192, layers=4).eval()
+HINT = 0
+for a in list(sys.argv[1:]):
+    if a.startswith("--hint="):
+        HINT = int(a.split("=")[1])
+        sys.argv.remove(a)
 for n, B, check in [(4096, 8, 2), (8192, 2, 1), (16384, 1, 1)]:
     if len(sys.argv) > 1 and str(n) not in sys.argv[1:]:
         continue
     Cs = np.stack([np.random.RandomState(42 + i).uniform(0, 1, (n, n)) for i in range(B)])
-    pipe = WarmStartPipeline(model, "cuda:0")
+    pipe = WarmStartPipeline(model, "cuda:0", threads_hint=HINT)
     C = torch.from_numpy(Cs).cuda()
     torch.cuda.synchronize()
     for rep in range(2):
@@ -24,7 +29,7 @@ for n, B, check in [(4096, 8, 2), (8192, 2, 1), (16384, 1, 1)]:
         dt = time.perf_counter() - t0
     st = out["stats"].cpu().numpy()
     ret = out["ret"].cpu().numpy()
-    print(f"n={n} B={B}: {dt*1e3:.1f} ms/batch  ret={ret.tolist()} branch={st[:,0].tolist()} paths={st[:,4].tolist()} "
+    print(f"hint={HINT} n={n} B={B}: {dt*1e3:.1f} ms/batch  ret={ret.tolist()} branch={st[:,0].tolist()} paths={st[:,4].tolist()} "
           f"steps={st[:,6].tolist()} kernel_ms={[round(v/1e5,1) for v in st[:,13]]} err={st[:,12].tolist()}", flush=True)
     u = out["u"].cpu().numpy().astype(np.float64); v = out["v"].cpu().numpy(); x = out["x"].cpu().numpy()
     for b in range(check):

@@ -8,9 +8,13 @@ sys.path[:0] = [str(ROOT), str(ROOT / "gnn-accelerated-lap-warm-start-pipeline_a
 import numpy as np, torch
 from gnn import OneGNN, WarmStartPipeline
 from solvers.generators import mixed_batch
-B, n = 32, 2048
+B, n = int(os.environ.get("DIAG_B", 32)), int(os.environ.get("DIAG_N", 2048))
 hint = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-Cs, fams = mixed_batch(B, n, seed=1234)
+if n > 2048:  # large-n anatomy: uniform instances only
+    Cs = np.stack([np.random.RandomState(42 + i).uniform(0, 1, (n, n)) for i in range(B)])
+    fams = ["uniform"] * B
+else:
+    Cs, fams = mixed_batch(B, n, seed=1234)
 torch.manual_seed(0)
 pipe = WarmStartPipeline(OneGNN(21, hidden=192, layers=4).eval(), "cuda:0", threads_hint=hint)
 C = torch.from_numpy(Cs).cuda()
@@ -23,6 +27,8 @@ print('ret nonzero:', int((ret != 0).sum()), 'err slots:', st[:,12].tolist()[:8]
 names = ["find", "relax:issue loads", "relax:wait+compute+publish", "relax:barrier", "relax:post", "n cnt0", "n cnt1", "n slow", "path end"]
 for f in ("uniform", "sparse", "clustered"):
     idx = [b for b in range(B) if fams[b] == f]
+    if not idx:
+        continue
     s = st[idx].mean(0)
     tot_ms = s[13] / 1e5
     print(f"{f}: kernel {tot_ms:.1f} ms, paths {s[4]:.0f} finds {s[5]:.0f} steps {s[6]:.0f}")
