@@ -1754,10 +1754,13 @@ __host__ __device__ int solver_row_slots(int n, int ch)
     return 0;
 }
 
-// n = 8192 -> 512 x 16, n = 16384 -> 512 x 32 (exact multiples only: the DMA pieces tile the row)
+// n = 8192 -> 512 threads x 16 positions, two row slots.  Measured (uniform instance, ms per solve):
+// n = 8192: 2,278 here against 2,658 with 1024 x 8 and the state in global memory (level 0);
+// n = 16384 (512 x 32, one slot): 51 s against 25 s for 1024 x 16 at level 0 -- the step time grows
+// with the positions per thread, so K5 stays on the generic path.
 bool large_row_geometry(int n, int *threads, int *ch)
 {
-    if (n != 8192 && n != 16384) return false;
+    if (n != 8192) return false;
     *threads = 512;
     *ch = n / 512;
     return solver_row_slots(n, *ch) >= 1;
@@ -1863,8 +1866,7 @@ hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t st
     if (threads_hint <= 0 && p.mode == kModeSeeded && large_row_geometry(p.n, &threads, &ch)) {
         if (!p.g_x) return hipErrorInvalidValue;
         const size_t lds8 = solver_lds_bytes(p.n, ch, 8);
-        if (ch == 16) return launch_one<16, 8, 512>(p, threads, lds8, stream);
-        return launch_one<32, 8, 512>(p, threads, lds8, stream);
+        return launch_one<16, 8, 512>(p, threads, lds8, stream);
     }
     int level = solver_lds_level(p.n, ch);
     if (level == 5 && (long long)threads * ch != (((long long)p.n + ch * 64 - 1) / (ch * 64)) * (ch * 64))
