@@ -721,8 +721,7 @@ struct Solver {
             }
             {
                 // owners of positions hi .. hi+3 publish the columns sitting there
-                const unsigned w0 = (unsigned)(b0 - hi);  // window index of our first position
-                if (w0 < (unsigned)kRecEvents || (unsigned)(b0 + CH - 1 - hi) < (unsigned)kRecEvents) {
+                if (b0 <= hi + kRecEvents - 1 && b0 + CH - 1 >= hi) {  // our positions overlap the window
 #pragma unroll
                     for (int r = 0; r < CH; ++r) {
                         const unsigned w = (unsigned)(b0 + r - hi);
