@@ -430,6 +430,9 @@ struct Solver {
         // app_pos + 1 -- the only two fresh entries the directly following step can look at
         int app_pos = -1, app_j = 0, app_i = 0, app_j1 = 0, app_i1 = 0;
         bool app_two = false;
+        // 2-4 tie events behind the single barrier: only with <= 4 positions per thread (with 8+
+        // the extra live values of that path spill: n = 16384 went from 25 s to 55 s with it)
+        constexpr bool kFastMulti = CH <= 4;
         bool pf_have = false;  // level 6: the current head's row sits in slot pf_slot
         int pf_slot = 0;
         double level = 0.0;
@@ -719,7 +722,7 @@ struct Solver {
                     pf_issued = true;
                 }
             }
-            {
+            if constexpr (kFastMulti) {
                 // owners of positions hi .. hi+3 publish the columns sitting there
                 if (b0 <= hi + kRecEvents - 1 && b0 + CH - 1 >= hi) {  // our positions overlap the window
 #pragma unroll
@@ -727,6 +730,12 @@ struct Solver {
                         const unsigned w = (unsigned)(b0 + r - hi);
                         if (w < (unsigned)kRecEvents && b0 + r < n) ctrl->a_pub[par][w] = jr[r];
                     }
+                }
+            } else {
+                if (hi >= b0 && hi < b0 + CH && hi < n) {
+#pragma unroll
+                    for (int r = 0; r < CH; ++r)
+                        if (b0 + r == hi) ctrl->a_pub[par][0] = jr[r];
                 }
             }
             const double v_head = v[head_j];
@@ -790,7 +799,28 @@ struct Solver {
                 }
             }
             const int seen = par ? seen1 : seen0;
-            if (my_events) {
+            if (my_events && !kFastMulti) {
+                // no returning atomic and no LDS read on this path: if this turns out to be the
+                // only event of the step the record is exactly right, otherwise nobody reads it
+                atomicAdd(&ctrl->ev_total[par], my_events);
+                EventSlot sl;
+                sl.j = 0;
+                sl.i = 0;
+#pragma unroll
+                for (int r = 0; r < CH; ++r) {
+                    if (r == ev_r) {
+                        sl.j = jr[r];
+                        if constexpr (CACHE_Y)
+                            sl.i = yr[r];
+                        else
+                            sl.i = y[jr[r]];
+                    }
+                }
+                sl.p = b0 + ev_r;
+                sl.a = 0;
+                ctrl->rec[par][0] = sl;
+            }
+            if (my_events && kFastMulti) {
                 // arrival slot of our first event (the counter is cumulative: `seen` is what it
                 // held when the step began); the first kRecEvents events of a step leave a record
                 int slot_idx = atomicAdd(&ctrl->ev_total[par], my_events) - seen;
@@ -899,7 +929,9 @@ struct Solver {
                 // P_s moves its column to hi+s and adopts the column published for hi+s.  A free
                 // column among the events ends the path at the first one in position order.
                 bool resolved = false;
-                if (cnt <= kRecEvents) {
+                // (with 8+ positions per thread the extra live values of this path spill: n = 16384
+                // went from 25 s to 55 s per instance with it -- those sizes keep the ordered replay)
+                if (kFastMulti && cnt <= kRecEvents) {
                     // Every lane reads the same records, so the values below are wave-uniform but
                     // deliberately kept in VECTOR registers: ranking them on the scalar unit is a
                     // long dependent chain (and spills SGPRs); only the few results that steer
