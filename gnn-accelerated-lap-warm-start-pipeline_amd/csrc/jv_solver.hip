@@ -433,6 +433,9 @@ struct Solver {
         // 2-4 tie events behind the single barrier: only with <= 4 positions per thread (with 8+
         // the extra live values of that path spill: n = 16384 went from 25 s to 55 s with it)
         constexpr bool kFastMulti = CH <= 4;
+#ifdef LAPWARM_DIAG_BARRIER
+        int diag_prev_cnt = -1;
+#endif
         bool pf_have = false;  // level 6: the current head's row sits in slot pf_slot
         int pf_slot = 0;
         double level = 0.0;
@@ -854,12 +857,24 @@ struct Solver {
             __syncthreads();
             STAMPR(tr3);
             STAMP_ADD(3, tr3, tr2);
+#ifdef LAPWARM_DIAG_BARRIER  // barrier wait by the event count of the PREVIOUS step (slots 9-12 reused)
+            if (diag_prev_cnt == 0) {
+                STAMP_ADD(9, tr3, tr2);
+                STAMP_INC(10);
+            } else if (diag_prev_cnt == 1) {
+                STAMP_ADD(11, tr3, tr2);
+                STAMP_INC(12);
+            }
+#endif
             // one LDS round trip for everything the post phase can need
             const int tot_raw = ctrl->ev_total[par];
             EventSlot sl = ctrl->rec[par][0];
             const int a_raw = ctrl->a_pub[par][0];
             const int tot = uni(tot_raw);
             const int cnt = tot - seen;
+#ifdef LAPWARM_DIAG_BARRIER
+            diag_prev_cnt = cnt;
+#endif
             if (par)
                 seen1 = tot;
             else

@@ -49,4 +49,7 @@ for f in ("uniform", "sparse", "clustered"):
     post2 = s[16+4] - s[16+13] - s[16+14]
     print(f"      post | cnt0 {s[16+13]/c0:7.0f}  cnt1 {s[16+14]/c1:7.0f}  slow path (free/multi) {post2/c2:7.0f} cycles each")
     print(f"      tie finds / finds        {s[16+15]/s[5]:8.3f}")
+    if os.environ.get("DIAG_BARRIER"):
+        print(f"      barrier wait after a 0-event step: {s[16+9]/max(s[16+10],1):7.0f} cycles ({s[16+10]:.0f} steps); "
+              f"after a 1-event step: {s[16+11]/max(s[16+12],1):7.0f} cycles ({s[16+12]:.0f} steps); all steps {s[16+3]/s[6]:7.0f}")
     print(f"   stamped total {total_cyc/1e6:.1f} Mcycles -> {total_cyc/ (tot_ms*1e-3) / 1e9:.2f} GHz-equivalent")
