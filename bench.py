@@ -161,9 +161,9 @@ def main():
         args.batch, args.n, args.families = 1, 16384, "uniform"
         args.cpu_sample = min(args.cpu_sample, 1)
     if args.steps is None:
-        args.steps = 1 if args.config == "K5" else 3
+        args.steps = 1 if args.config == "K5" else 10
     if args.warmup is None:
-        args.warmup = 1
+        args.warmup = 1 if args.config == "K5" else 3
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
