@@ -229,6 +229,27 @@ def test_shard_bounds_cover_the_batch():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_solver_lds_plan_fits_the_cu_for_every_size():
+    """Whatever LDS level the launcher picks for a size, the byte count it will request must fit the
+    160 KiB of a CU (a mis-sized level fails at launch with 'invalid argument' on the GPU only).
+    Internal C++ symbols of the library, by their mangled names."""
+    import ctypes as ct
+    from lap import _hip
+    lib = _hip.load()
+    level = lib._ZN7lapwarm16solver_lds_levelEii
+    level.restype, level.argtypes = ct.c_int, [ct.c_int, ct.c_int]
+    nbytes = lib._ZN7lapwarm16solver_lds_bytesEiii
+    nbytes.restype, nbytes.argtypes = ct.c_size_t, [ct.c_int, ct.c_int, ct.c_int]
+    seen = set()
+    for n in list(range(1, 600)) + list(range(600, 16385, 37)) + [2048, 3634, 3635, 4096, 4427, 4428, 8192, 16384]:
+        for ch in (1, 2, 4, 8, 16):
+            lv = level(n, ch)
+            seen.add(lv)
+            assert nbytes(n, ch, lv) <= 160 * 1024, (n, ch, lv, nbytes(n, ch, lv))
+    assert {0, 1, 2} <= seen
+    assert nbytes(8192, 16, 8) <= 160 * 1024  # the 512 x 16 large-row geometry (two row slots)
+
+
 def test_solver_geometry_and_timing_helper():
     from solvers import time_solver_rigorous
     calls = []
