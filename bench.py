@@ -252,6 +252,9 @@ def main():
         achieved = alg_bytes / (solver_avg_ms * 1e-3) / 1e9
         branches = {int(k): int(c) for k, c in zip(*np.unique(stats[:, 0], return_counts=True))}
         cus_busy = min(B, N_CUS)  # one workgroup = one instance = one CU
+        from lap import _hip as _h
+        helpers = bool(_h.load().lapwarm_solver_uses_helpers(n))
+        cus_kernel = min(2 * B, N_CUS) if helpers else cus_busy  # + one (mostly idle) helper CU per instance
         line = {
             "metric": "LAP instances/sec (whole node), n=%d warm-start pipeline" % n,
             "value": round(value, 3),
@@ -279,6 +282,7 @@ def main():
                                   if overlap else "none (stages back to back on one stream)"),
                 "solver_threads_hint": args.threads_hint,
                 "solver_search": os.environ.get("LAPWARM_SEARCH", "legacy"),
+                "solver_helper_workgroups": helpers,
                 "branches": branches,
                 "ret_nonzero": int((ret != 0).sum()),
             },
@@ -292,12 +296,14 @@ def main():
                 "traffic": recorded_traffic() if args.config == "K3" and (B, n) == (32, 2048) else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(solver_avg_ms, 3),
-                "cus_occupied": cus_busy,
+                "cus_occupied": cus_kernel,
+                "cus_solving": cus_busy,
                 "cus_total": N_CUS,
                 "per_cu_GBps": round(achieved / cus_busy, 3),
-                "note": "latency-bound chain of dependent row scans on ONE CU per instance (the kernel occupies "
-                        "cus_occupied of cus_total CUs; a CU pulls ~25 GB/s from HBM at best, "
-                        "tools/micro/mlp_bench.hip); achieved = 8*E/launch time with E counted by the kernel; "
+                "note": "latency-bound chain of dependent row scans on ONE CU per instance (cus_solving); with "
+                        "solver_helper_workgroups a second, mostly idle workgroup per instance pulls announced "
+                        "rows into the shared L2 (cus_occupied of cus_total CUs); a CU pulls ~25 GB/s from HBM at "
+                        "best, tools/micro/mlp_bench.hip; achieved = 8*E/launch time with E counted by the kernel; "
                         "traffic = HBM bytes per launch from separate rocprofv3 --pmc passes "
                         "(profiles/*_pmc_traffic.txt, 2*FETCH_SIZE+WRITE_SIZE)",
             },

@@ -136,6 +136,8 @@ struct Solver {
     int *order, *pred, *y, *x, *fr;
     cols::Layout clay;  // column-owned search (levels 3-5): cols_search.hpp
     cols::Ctl *cctl;
+    int *ring;     // helper experiment: ring of upcoming head rows (null: off)
+    int ring_count;
     unsigned char *slots;  // levels 6, 8: row slots of slot_bytes each
     int slot_bytes;
     int nslots;
@@ -158,6 +160,41 @@ struct Solver {
 #endif
 
     __device__ __forceinline__ int base() const { return bc.tid * CH; }
+
+    // Announce the row of a column that just joined the SCAN list (or the start row of the next
+    // path) to the helper workgroup.  Called by every thread with the same argument: ring_count is
+    // uniform, thread 0 stores.  One word per slot carries its own generation, so no ordering
+    // between two stores is needed.
+    __device__ __forceinline__ void ring_push(int row)
+    {
+        if (ring && (unsigned)row < (unsigned)n) {
+            if (bc.tid == 0) {
+                const int gen = (ring_count >> 6) + 1;
+                __hip_atomic_store(&ring[2 + (ring_count & (kRingSlots - 1))], (gen << 16) | row, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ++ring_count;
+        }
+    }
+    // ... and the rows of the SCAN entries lo+1 .. hi-1 after a minima collection with ties (the
+    // head at lo is needed at once; the others have a lead).  Wave 0 stores, one entry per lane.
+    __device__ __forceinline__ void ring_push_scan(int lo, int hi)
+    {
+        if (!ring) return;
+        int cnt = hi - lo - 1;
+        if (cnt <= 0) return;
+        cnt = (cnt < kRingSlots - 2) ? cnt : kRingSlots - 2;
+        if (bc.wave == 0 && bc.lane < cnt) {
+            const int j = order[lo + 1 + bc.lane];
+            const int i = ((unsigned)j < (unsigned)n) ? y[j] : -1;
+            const int c = ring_count + bc.lane;
+            const int gen = (c >> 6) + 1;
+            // (an unmatched column ends the path when it is reached: nothing to fetch)
+            const int word = (gen << 16) | (((unsigned)i < (unsigned)n) ? i : 0xffff);
+            __hip_atomic_store(&ring[2 + (c & (kRingSlots - 1))], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ring_count += cnt;
+    }
 
     __device__ __forceinline__ void fence_if_global()
     {
@@ -543,6 +580,8 @@ struct Solver {
                 // on alone and corrupt the search (found with tools/stress_determinism.py: ~1 run
                 // in 100-300 ended in a consistency guard; 0 in 900 with this order).
                 const int min_row_raw = y[min_col];
+                // the likely next head (certain without ties), a whole collection tail ahead of its use
+                ring_push(uni(min_row_raw));
                 STAMP_FI(4, tfd);
                 STAMP_ADD(11, tfd, tfc);
                 __syncthreads();
@@ -594,6 +633,7 @@ struct Solver {
                     STAMP_ADD(14, tfg, tfe);
                     STAMP_INC(15);
                     if (target >= 0) break;
+                    ring_push_scan(lo, hi);
                     // the collection permuted order[]: rebind the registers of the positions we own
 #pragma unroll
                     for (int r = 0; r < CH; ++r) {
@@ -926,6 +966,7 @@ struct Solver {
                 app_pos = hi;
                 app_j = sl.j;
                 app_i = sl.i;
+                ring_push(sl.i);
                 ++hi;
                 ++lo;
                 if (queued) {
@@ -1039,6 +1080,17 @@ struct Solver {
                         app_j1 = uni(second_j);
                         app_i1 = uni(second_i);
                         app_two = true;
+                        ring_push(app_i);
+                        ring_push(app_i1);
+                        if (cnt > 2) {
+                            int third_i = sl.i, fourth_i = sl.i;
+                            third_i = (r1 == 2) ? e1.i : third_i, third_i = (r2 == 2) ? e2.i : third_i;
+                            third_i = (r3 == 2) ? e3.i : third_i;
+                            fourth_i = (r1 == 3) ? e1.i : fourth_i, fourth_i = (r2 == 3) ? e2.i : fourth_i;
+                            fourth_i = (r3 == 3) ? e3.i : fourth_i;
+                            ring_push(uni(third_i));
+                            if (cnt > 3) ring_push(uni(fourth_i));
+                        }
                         hi += cnt;
                         ++lo;
                         if (queued) {
@@ -1056,11 +1108,13 @@ struct Solver {
                     STAMP_ADD(4, tr4m, tr3);
                     continue;
                 }
+                const int hi_before = hi;
                 if (bc.wave == 0) replay_scan(hi, par);
                 __syncthreads();
                 hi = uni(ctrl->hi);
                 target = uni(ctrl->target);
                 if (target >= 0) break;
+                ring_push_scan(hi_before - 1, hi);
                 ++lo;
                 if (queued) {
                     head_j = uni(nq_j);
@@ -1125,6 +1179,7 @@ struct Solver {
                 err = 2;
                 break;
             }
+            if (f + 1 < n_free) ring_push(uni(fr[f + 1]));  // the helper fetches it while this path runs
             int target;
             if constexpr (COLS) {
                 // ends with a barrier (pred[] is dumped at the end)
@@ -1506,8 +1561,51 @@ template <int CH, int LDSL, int TB>
 __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int b = blockIdx.x;
     const int n = p.n;
+    if (blockIdx.x >= (unsigned)p.batch) {
+        // ---- helper workgroup of instance blockIdx.x - batch (same XCD when batch % 8 == 0: the
+        // dispatcher deals workgroups to the 8 XCDs round robin): wave 0 pulls the announced rows
+        // towards the shared L2 with LDS-DMA requests into a dummy area; nothing reads them here.
+        // Exits on the solver's done flag, or after 0.5 s whatever happens.
+        if (threadIdx.x >= kWave) return;
+        const int hb = (int)blockIdx.x - p.batch;
+        int *ring = p.pf_ring + (size_t)hb * kRingInts;
+        const double *Cb = p.C + (size_t)hb * n * n;
+        const int lane = threadIdx.x;
+        const unsigned dummy = cols::lds_address(smem);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+        int seen = 0;
+        const int pieces = (n * 8 + 1023) / 1024;
+        while (true) {
+            const int w = __hip_atomic_load(&ring[2 + (seen & (kRingSlots - 1))], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int expect = ((seen >> 6) + 1) & 0xffff;
+            const int got = (w >> 16) & 0xffff;
+            if (got == expect) {
+                const int row = w & 0xffff;
+                if (row < n) {
+                    const double *r = Cb + (size_t)row * n;
+                    for (int k = 0; k < pieces; ++k) {
+                        int col = k * 128 + lane * 2;
+                        col = (col < n - 2) ? col : n - 2;
+                        cols::dma_request16(r + col, dummy);
+                    }
+                }
+                ++seen;
+                continue;
+            }
+            const int ahead = (got - expect) & 0xffff;
+            if (got != 0 && ahead != 0 && ahead < 0x8000) {  // the solver lapped us: skip a ring's worth
+                seen += kRingSlots * ahead;
+                continue;
+            }
+            if (__hip_atomic_load(&ring[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        cols::dma_wait<0>();
+        return;
+    }
+    const int b = blockIdx.x;
     const int W = (n + 31) >> 5;
     const int Wpad = (W + 1) & ~1;
 
@@ -1621,6 +1719,8 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         s.clay.tmpcol = off(s.tmpcol);
         s.clay.ex = off(ex);
     }
+    s.ring = (p.helper && p.pf_ring) ? p.pf_ring + (size_t)b * kRingInts : nullptr;
+    s.ring_count = 0;
     s.scan_elems = s.init_elems = s.colred_elems = 0;
     s.paths = s.finds = s.scan_steps = s.arr_iters = s.transfer_rows = s.arr_fired = 0;
     s.step_id = 1;
@@ -1637,6 +1737,8 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
     const int flags = p.inst_flags ? p.inst_flags[b] : 0;
     if (p.mode == kModeSeeded && (flags & kFlagInfeasible)) {
         if (tid == 0) {
+            if (p.helper && p.pf_ring)
+                __hip_atomic_store(&p.pf_ring[(size_t)b * kRingInts], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             p.ret[b] = -3;
             if (p.stats) {
                 for (int q = 0; q < kStatsPerInstance; ++q) p.stats[(size_t)b * kStatsPerInstance + q] = 0;
@@ -1728,6 +1830,8 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         }
     }
     if (tid == 0) {
+        if (p.helper && p.pf_ring)
+            __hip_atomic_store(&p.pf_ring[(size_t)b * kRingInts], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         p.ret[b] = err ? (-100 - err) : 0;
         if (p.stats) {
             long long *st = p.stats + (size_t)b * kStatsPerInstance;
@@ -1778,7 +1882,7 @@ hipError_t launch_one(const SolverParams &p, int threads, size_t lds_bytes, hipS
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(p.batch), dim3(threads), lds_bytes, stream, p);
+    hipLaunchKernelGGL(kern, dim3(p.batch * (p.helper ? 2 : 1)), dim3(threads), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
@@ -1898,8 +2002,21 @@ void solver_geometry(int n, int threads_hint, int *threads, int *ch)
     *ch = c;
 }
 
-hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t stream)
+// Helper workgroups: rows of 8-32 KiB (n = 1024 .. 4096, even).  Measured on the same box, solver
+// kernel per launch: K3 79.6 -> 73.2 ms, K4 slice 327.8 -> 276.0 ms, K2 (n = 512) no change.
+bool solver_uses_helpers(int n)
 {
+    static const int want = [] {
+        const char *e = getenv("LAPWARM_HELPER");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return want && n >= 1024 && n <= 4096 && n % 2 == 0;
+}
+
+hipError_t launch_solver(const SolverParams &p_in, int threads_hint, hipStream_t stream)
+{
+    SolverParams p = p_in;
+    p.helper = (p.mode == kModeSeeded && p.pf_ring && solver_uses_helpers(p.n)) ? 1 : 0;
     int threads, ch;
     // measured (n=2048, ARR-dominated cold solve): 512 threads 2.6 us/iteration, 1024: 3.2, 256: 3.1
     if (threads_hint <= 0 && p.mode == kModeCold && p.n > 1024 && p.n <= 2048) threads_hint = 512;

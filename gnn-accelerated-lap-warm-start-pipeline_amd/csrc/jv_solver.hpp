@@ -42,13 +42,20 @@ struct SolverParams {
     // per-instance state in global memory, only used when the state does not fit LDS
     double *g_dist, *g_v;
     int *g_order, *g_pred, *g_y, *g_x, *g_fr, *g_evl, *g_tmpcol;
+    // helper workgroups (EXPERIMENT, LAPWARM_HELPER=1): [batch][kRingInts] ring of upcoming head
+    // rows, zeroed by the caller; word 0 = done flag, words 2.. = (generation << 16 | row)
+    int *pf_ring;
+    int helper;
 };
+constexpr int kRingSlots = 64;
+constexpr int kRingInts = 2 + kRingSlots;
 
 size_t solver_lds_bytes(int n, int ch, int level);
 int solver_lds_level(int n, int ch);
 bool solver_needs_global_state(int n);
 void solver_geometry(int n, int threads_hint, int *threads, int *ch);
 hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t stream);
+bool solver_uses_helpers(int n);  // seeded mode with a ring: one helper workgroup per instance
 
 // ---- dense sweeps (dense_sweeps.hip) ----------------------------------------------------
 struct PreludeParams {

@@ -51,6 +51,7 @@ struct SeededWs {
     uint32_t *tight_bits;
     double *g_dist, *g_v;
     int *g_order, *g_pred, *g_y, *g_x, *g_fr, *g_evl, *g_tmpcol;
+    int *pf_ring;
     size_t bytes;
 };
 
@@ -67,6 +68,7 @@ SeededWs carve_seeded(void *ws, int batch, int n)
     s.tight_cnt = c.take<int>(bn);
     s.flags = c.take<int>((size_t)batch);
     s.tight_bits = c.take<uint32_t>(bn * W);
+    s.pf_ring = c.take<int>((size_t)batch * kRingInts);
     if (solver_needs_global_state(n)) {
         s.g_dist = c.take<double>(bn);
         s.g_v = c.take<double>(bn);
@@ -183,6 +185,8 @@ int lapwarm_refine_aggregate_batched(const float *topk16, const float *u_pre, co
     return lapwarm_refine_aggregate_wsum(topk16, u_pre, w1, b1, out, nullptr, rows, H, stream_);
 }
 
+int lapwarm_solver_uses_helpers(int n) { return solver_uses_helpers(n) ? 1 : 0; }
+
 const char *lapwarm_build_info(void) { return "liblapwarm_hip gfx950 (hand-written HIP, fp64)"; }
 
 size_t lapwarm_seeded_workspace_bytes(int batch, int n)
@@ -215,6 +219,7 @@ int lapwarm_seeded_batched(const double *C, int batch, int n, const double *u_se
     HIP_TRY(hipMemcpyAsync(w.u_work, u_seed, vec, hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemcpyAsync(w.v_work, v_seed, vec, hipMemcpyDeviceToDevice, stream));
     HIP_TRY(hipMemsetAsync(w.flags, 0, sizeof(int) * (size_t)batch, stream));
+    HIP_TRY(hipMemsetAsync(w.pf_ring, 0, sizeof(int) * (size_t)batch * kRingInts, stream));
 
     PreludeParams pp;
     pp.C = C;
@@ -260,6 +265,7 @@ int lapwarm_seeded_batched(const double *C, int batch, int n, const double *u_se
     sp.g_fr = w.g_fr;
     sp.g_evl = w.g_evl;
     sp.g_tmpcol = w.g_tmpcol;
+    sp.pf_ring = w.pf_ring;
     HIP_TRY(profile_begin(stream));
     HIP_TRY(launch_solver(sp, threads_hint, stream));
     HIP_TRY(profile_end(stream));

@@ -143,6 +143,11 @@ int lapwarm_refine_aggregate_wsum(const float *topk16, const float *u_pre, const
 void lapwarm_profile_enable(int on);
 double lapwarm_profile_last_solver_ms(void);
 
+/* 1 when lapwarm_seeded_batched launches one helper workgroup per instance for this n (the helper
+ * pulls announced head rows towards the L2 its solver shares; LAPWARM_HELPER=0 turns it off):
+ * the solver kernel then occupies 2 * batch CUs. */
+int lapwarm_solver_uses_helpers(int n);
+
 /* Misc */
 const char *lapwarm_last_error(void);
 int lapwarm_device_count(void);
