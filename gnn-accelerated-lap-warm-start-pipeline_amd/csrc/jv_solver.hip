@@ -1568,7 +1568,8 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         // towards the shared L2 with LDS-DMA requests into a dummy area; nothing reads them here.
         // Exits on the solver's done flag, or after 0.5 s whatever happens.
         if (threadIdx.x >= kWave) return;
-        const int hb = (int)blockIdx.x - p.batch;
+        const int hsel = (int)blockIdx.x / p.batch - 1;  // which of the p.helper helpers of the instance
+        const int hb = (int)blockIdx.x % p.batch;
         int *ring = p.pf_ring + (size_t)hb * kRingInts;
         const double *Cb = p.C + (size_t)hb * n * n;
         const int lane = threadIdx.x;
@@ -1584,7 +1585,7 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
                 const int row = w & 0xffff;
                 if (row < n) {
                     const double *r = Cb + (size_t)row * n;
-                    for (int k = 0; k < pieces; ++k) {
+                    for (int k = hsel; k < pieces; k += p.helper) {
                         int col = k * 128 + lane * 2;
                         col = (col < n - 2) ? col : n - 2;
                         cols::dma_request16(r + col, dummy);
@@ -1882,7 +1883,7 @@ hipError_t launch_one(const SolverParams &p, int threads, size_t lds_bytes, hipS
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(p.batch * (p.helper ? 2 : 1)), dim3(threads), lds_bytes, stream, p);
+    hipLaunchKernelGGL(kern, dim3(p.batch * (1 + p.helper)), dim3(threads), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
@@ -2016,7 +2017,12 @@ bool solver_uses_helpers(int n)
 hipError_t launch_solver(const SolverParams &p_in, int threads_hint, hipStream_t stream)
 {
     SolverParams p = p_in;
-    p.helper = (p.mode == kModeSeeded && p.pf_ring && solver_uses_helpers(p.n)) ? 1 : 0;
+    static const int n_helpers = [] {
+        const char *e = getenv("LAPWARM_HELPERS_PER_INSTANCE");
+        const int k = e ? atoi(e) : 1;
+        return (k >= 1 && k <= 4) ? k : 1;
+    }();
+    p.helper = (p.mode == kModeSeeded && p.pf_ring && solver_uses_helpers(p.n)) ? n_helpers : 0;
     int threads, ch;
     // measured (n=2048, ARR-dominated cold solve): 512 threads 2.6 us/iteration, 1024: 3.2, 256: 3.1
     if (threads_hint <= 0 && p.mode == kModeCold && p.n > 1024 && p.n <= 2048) threads_hint = 512;
