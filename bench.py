@@ -255,6 +255,7 @@ def main():
         from lap import _hip as _h
         helpers = bool(_h.load().lapwarm_solver_uses_helpers(n))
         cus_kernel = min(2 * B, N_CUS) if helpers else cus_busy  # + one (mostly idle) helper CU per instance
+        # (the grid pads the batch to a multiple of 8 so that helper and solver share an XCD; padding exits at once)
         line = {
             "metric": "LAP instances/sec (whole node), n=%d warm-start pipeline" % n,
             "value": round(value, 3),

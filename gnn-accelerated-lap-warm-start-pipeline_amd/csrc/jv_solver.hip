@@ -1567,9 +1567,14 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         // dispatcher deals workgroups to the 8 XCDs round robin): wave 0 pulls the announced rows
         // towards the shared L2 with LDS-DMA requests into a dummy area; nothing reads them here.
         // Exits on the solver's done flag, or after 0.5 s whatever happens.
+        // grid layout: [0, batch) solvers; then regions of P = batch rounded up to 8 workgroups, one
+        // per helper copy, so that helper and solver of an instance have the same index modulo 8
         if (threadIdx.x >= kWave) return;
-        const int hsel = (int)blockIdx.x / p.batch - 1;  // which of the p.helper helpers of the instance
-        const int hb = (int)blockIdx.x % p.batch;
+        const int P = (p.batch + 7) & ~7;
+        if ((int)blockIdx.x < P) return;  // padding between the solvers and the first helper region
+        const int hsel = ((int)blockIdx.x - P) / P;  // which of the p.helper helpers of the instance
+        const int hb = ((int)blockIdx.x - P) % P;
+        if (hb >= p.batch) return;
         int *ring = p.pf_ring + (size_t)hb * kRingInts;
         const double *Cb = p.C + (size_t)hb * n * n;
         const int lane = threadIdx.x;
@@ -1600,7 +1605,7 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
                 continue;
             }
             if (__hip_atomic_load(&ring[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > (n <= 4096 ? 50000000ull : 6000000000ull)) break;  // 0.5 s / 60 s
             __builtin_amdgcn_s_sleep(1);
         }
         cols::dma_wait<0>();
@@ -1883,7 +1888,8 @@ hipError_t launch_one(const SolverParams &p, int threads, size_t lds_bytes, hipS
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kern, dim3(p.batch * (1 + p.helper)), dim3(threads), lds_bytes, stream, p);
+    const int padded = (p.batch + 7) & ~7;  // helpers sit at the same index modulo 8 (= same XCD) as their solver
+    hipLaunchKernelGGL(kern, dim3(p.helper ? padded * (1 + p.helper) : p.batch), dim3(threads), lds_bytes, stream, p);
     return hipGetLastError();
 }
 
@@ -2003,15 +2009,20 @@ void solver_geometry(int n, int threads_hint, int *threads, int *ch)
     *ch = c;
 }
 
-// Helper workgroups: rows of 8-32 KiB (n = 1024 .. 4096, even).  Measured on the same box, solver
-// kernel per launch: K3 79.6 -> 73.2 ms, K4 slice 327.8 -> 276.0 ms, K2 (n = 512) no change.
+// Helper workgroups: rows of 8-64 KiB (n = 1024 .. 8192, even).  Measured on the same box, solver
+// kernel per launch: K3 79.6 -> 73.2 ms, K4 slice 327.8 -> 276.0 ms, n = 8192 2.28 -> 2.09 s,
+// K2 (n = 512) no change, n = 16384 worse.
 bool solver_uses_helpers(int n)
 {
     static const int want = [] {
         const char *e = getenv("LAPWARM_HELPER");
         return (e && e[0] == '0') ? 0 : 1;
     }();
-    return want && n >= 1024 && n <= 4096 && n % 2 == 0;
+    static const int max_n = [] {
+        const char *e = getenv("LAPWARM_HELPER_MAX_N");
+        return e ? atoi(e) : 8192;  // n = 16384: 29.3 s with a helper against 25.6 s without
+    }();
+    return want && n >= 1024 && n <= max_n && n % 2 == 0;
 }
 
 hipError_t launch_solver(const SolverParams &p_in, int threads_hint, hipStream_t stream)
