@@ -10,8 +10,8 @@
 //
 // Design (not a translation of the serial code):
 //   * all O(n) solver state (dist, v, column order, pred, x, y, free list) lives in LDS
-//     (36 n bytes: 72 KiB at n=2048, 144 KiB at n=4096 of the CU's 160 KiB); larger n use a
-//     per-instance global workspace that stays L2 resident;
+//     (44 n bytes + bitmaps: 91 KiB at n=2048; x and the free list move to global memory above
+//     n = 3,634, everything above n = 4,427 -- solver_lds_bytes() is the authority);
 //   * every thread owns CH consecutive POSITIONS of the column order.  One relax step is one
 //     pass over the TODO positions: gather C[i][col], v[col], dist[col], update, and keep the
 //     new distances in registers;
@@ -29,8 +29,13 @@
 //     compare), and a step with exactly one tie event -- the common case -- is resolved with a
 //     single barrier: the finder publishes (column, position, matched row, displaced column) in
 //     a double-buffered LDS slot, every thread advances the uniform state from it, and only the
-//     owner of the affected position touches order[].  Steps with several events fall back to
-//     the ordered replay by wave 0.
+//     owner of the affected position touches order[].  Steps with 2-4 events are resolved the same
+//     way from arrival-slot records (round 2); more events, or events inside the swap window,
+//     fall back to the ordered replay by wave 0.
+//   * round 2: one HELPER workgroup per instance (blocks beyond the batch, same XCD) pulls the rows
+//     the solver announces through a ring in global memory -- columns joining the SCAN list, the
+//     winner of a minima collection, the next path's start row -- into the L2 both share.  It writes
+//     nothing the solver reads.  DESIGN.md section 4 has the measurements and the happens-before table.
 #include <stdlib.h>
 #include <string.h>
 
