@@ -2038,7 +2038,11 @@ hipError_t launch_solver(const SolverParams &p_in, int threads_hint, hipStream_t
         const int k = e ? atoi(e) : 1;
         return (k >= 1 && k <= 4) ? k : 1;
     }();
-    p.helper = (p.mode == kModeSeeded && p.pf_ring && solver_uses_helpers(p.n)) ? n_helpers : 0;
+    // (a helper can only help while its solver runs: with more workgroups than CUs the helpers would
+    // be dispatched after the solvers they serve and leave at once -- skip them)
+    p.helper = (p.mode == kModeSeeded && p.pf_ring && solver_uses_helpers(p.n) && p.batch * (1 + n_helpers) <= 256)
+                   ? n_helpers
+                   : 0;
     int threads, ch;
     // measured (n=2048, ARR-dominated cold solve): 512 threads 2.6 us/iteration, 1024: 3.2, 256: 3.1
     if (threads_hint <= 0 && p.mode == kModeCold && p.n > 1024 && p.n <= 2048) threads_hint = 512;
