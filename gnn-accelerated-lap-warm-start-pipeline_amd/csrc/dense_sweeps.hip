@@ -715,6 +715,35 @@ __global__ void __launch_bounds__(kSweepThreads, 6) row_features_kernel(FeatureP
 
 }  // namespace
 
+// One launch instead of two device-to-device copies and two memsets in front of the prelude: the
+// working copies of the seeds, the per-instance flags and the helper ring.  (A kernel is also what
+// a captured HIP graph replays most reliably: the runtime's memset nodes were seen to leave stale
+// flags behind on replay, tools/diag_graph.py.)
+__global__ void __launch_bounds__(kSweepThreads)
+seed_prepare_kernel(const double *u_seed, const double *v_seed, double *u_work, double *v_work, size_t count,
+                    int *flags, int n_flags, int *ring, int n_ring)
+{
+    const size_t gid = (size_t)blockIdx.x * kSweepThreads + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * kSweepThreads;
+    for (size_t k = gid; k < count; k += stride) {
+        u_work[k] = u_seed[k];
+        v_work[k] = v_seed[k];
+    }
+    for (size_t k = gid; k < (size_t)n_flags; k += stride) flags[k] = 0;
+    for (size_t k = gid; k < (size_t)n_ring; k += stride) ring[k] = 0;
+}
+
+hipError_t launch_seed_prepare(const double *u_seed, const double *v_seed, double *u_work, double *v_work,
+                               size_t count, int *flags, int n_flags, int *ring, int n_ring, hipStream_t stream)
+{
+    size_t blocks = (count + kSweepThreads - 1) / kSweepThreads;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(seed_prepare_kernel, dim3((unsigned)blocks), dim3(kSweepThreads), 0, stream, u_seed, v_seed,
+                       u_work, v_work, count, flags, n_flags, ring, n_ring);
+    return hipGetLastError();
+}
+
 hipError_t launch_prelude(const PreludeParams &p, hipStream_t stream)
 {
     if (p.n > 16384) return hipErrorInvalidValue;

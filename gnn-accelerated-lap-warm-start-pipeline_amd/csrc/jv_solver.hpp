@@ -72,6 +72,8 @@ struct PreludeParams {
     int *inst_flags;
 };
 hipError_t launch_prelude(const PreludeParams &p, hipStream_t stream);
+hipError_t launch_seed_prepare(const double *u_seed, const double *v_seed, double *u_work, double *v_work,
+                               size_t count, int *flags, int n_flags, int *ring, int n_ring, hipStream_t stream);
 
 // Gauss-Seidel projection of (u, v) for the instances flagged kFlagHasViolation; in place.
 hipError_t launch_projection(const double *C, int n, int batch, double *u, double *v,

@@ -215,11 +215,8 @@ int lapwarm_seeded_batched(const double *C, int batch, int n, const double *u_se
         snprintf(g_err, sizeof(g_err), "workspace too small: %zu < %zu", workspace_bytes, w.bytes);
         return -1;
     }
-    const size_t vec = sizeof(double) * (size_t)batch * n;
-    HIP_TRY(hipMemcpyAsync(w.u_work, u_seed, vec, hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(w.v_work, v_seed, vec, hipMemcpyDeviceToDevice, stream));
-    HIP_TRY(hipMemsetAsync(w.flags, 0, sizeof(int) * (size_t)batch, stream));
-    HIP_TRY(hipMemsetAsync(w.pf_ring, 0, sizeof(int) * (size_t)batch * kRingInts, stream));
+    HIP_TRY(launch_seed_prepare(u_seed, v_seed, w.u_work, w.v_work, (size_t)batch * n, w.flags, batch, w.pf_ring,
+                                batch * kRingInts, stream));
 
     PreludeParams pp;
     pp.C = C;
