@@ -33,7 +33,9 @@ for p in (str(ROOT), str(PKG)):
         sys.path.insert(0, p)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
+
+# torch is imported inside run_rank(): the --gpus N launcher below must start its rank processes
+# before this process has made any GPU call (and it never makes one itself)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_CUS = 256
@@ -73,6 +75,7 @@ def cpu_pipeline_once(C_b, sd, u_given=None):
 
 def cpu_baseline(C_host, sd, sample_idx, u_given=None):
     """One thread (the reference's methodology pins 1 thread, scripts/gnn_benchmark.py:26-31)."""
+    import torch
     torch.set_num_threads(1)
     t0 = time.perf_counter()
     outs = [cpu_pipeline_once(C_host[b], sd, None if u_given is None else u_given[b]) for b in sample_idx]
@@ -123,6 +126,55 @@ def cpu_baseline_node(B, n, fams, seed, hidden, layers, per_proc=2):
     return total / slowest, cores, total, slowest, wall
 
 
+def launch_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: start N rank processes (one per GPU)
+    through torch.distributed.run and forward rank 0's JSON line.  This parent process never touches
+    the GPU (no torch.cuda call, liblapwarm_hip.so not loaded) and never exec()s: the ranks are
+    children, their exit code is ours, and a line whose n_gpus differs from N is an error."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for raw in proc.stdout:
+        sys.stdout.write(raw)
+        sys.stdout.flush()
+        t = raw.strip()
+        if t.startswith("{") and '"n_gpus"' in t:
+            try:
+                line = json.loads(t)
+            except ValueError:
+                pass
+    rc = proc.wait()
+    if rc != 0:
+        print("bench.py: a rank process failed (exit code %d)" % rc, file=sys.stderr)
+        return rc
+    if line is None or line.get("n_gpus") != n_ranks:
+        print("bench.py: expected one JSON line with n_gpus == %d, got %r" % (
+            n_ranks, None if line is None else line.get("n_gpus")), file=sys.stderr)
+        return 3
+    return 0
+
+
+def standin_pipeline(C_host):
+    """--standin: a CPU stand-in for the device pipeline (row-wise argmin, NOT a solve) so that the
+    launcher / rendezvous / gather / JSON flow can be rehearsed where there is no GPU
+    (tests/test_bench_launcher.py).  Its JSON line says so and can never be read as a measurement."""
+    import torch
+    x = torch.from_numpy(np.argmin(C_host, axis=2).astype(np.int64))
+
+    def solve_local():
+        return {"x": x.clone()}
+    return solve_local
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -151,7 +203,26 @@ def main():
                     help="K3 (default) is the configuration the metric is quoted on; K2 / K4 / K5 are the other "
                          "single-GPU-sized BASELINE configs (K4 = one GPU's 32-instance slice of batch 256; "
                          "K5 = n=16384 large-n stress, batch 1)")
+    ap.add_argument("--standin", action="store_true",
+                    help="launcher rehearsal without a GPU: CPU stand-in instead of the device pipeline, gloo "
+                         "backend, tiny sizes; the JSON line is marked as a rehearsal, not a measurement")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        # no torchrun around us: become the launcher (before anything below can touch a GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if world_env is not None and int(world_env) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: the flag and the launcher disagree"
+                         % (args.gpus, world_env))
+    run_rank(args)
+
+
+def run_rank(args):
+    import torch
+    if args.standin:
+        return run_rank_standin(args)
     if args.config == "K2":    # batch=64 n=512 uniform, optimal-dual seeds instead of the GNN
         args.batch, args.n, args.families = 64, 512, "uniform"
     elif args.config == "K4":  # batch=256 n=4096 over 8 GPUs -> 32 per GPU
@@ -372,6 +443,41 @@ def main():
                 "note": "NOT the metric: %d independent K3 batches on separate HIP streams per step" % args.inflight,
             }
         print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+def run_rank_standin(args):
+    """The multi-rank flow of run_rank() with the CPU stand-in: same run_sharded(), same gather, same
+    JSON keys; backend gloo, no GPU, no library."""
+    import torch
+    import torch.distributed as dist
+    from gnn.bench_core import run_sharded
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    if os.environ.get("LAPWARM_STANDIN_FAIL_RANK") == str(rank):  # test hook: a rank that dies
+        raise SystemExit(7)
+    B, n = min(args.batch, 4), min(args.n, 32)
+    C_host = np.stack([np.random.RandomState(42 + rank * B + i).uniform(0, 1, (n, n)) for i in range(B)])
+    steps = args.steps if args.steps is not None else 2
+    warmup = args.warmup if args.warmup is not None else 1
+    out, elapsed = run_sharded(standin_pipeline(C_host), steps, warmup, distributed=distributed,
+                               gather_on_host=True)
+    if rank == 0:
+        gathered = out["x_all"] if distributed else out["x"]
+        assert tuple(gathered.shape) == (B * world, n)
+        print(json.dumps({
+            "metric": "REHEARSAL (bench.py --standin): launcher + gloo gather only, not a measurement",
+            "value": None, "unit": "instances/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * elapsed / steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "standin",
+            "config": {"workload": "stand-in (row argmin on CPU), batch=%d/rank n=%d" % (B, n),
+                       "global_batch": B * world, "parallelism": "batch-sharded x%d, one gloo gather" % world},
+        }), flush=True)
     if distributed:
         dist.destroy_process_group()
 
