@@ -353,7 +353,6 @@ def run_rank(args):
                 "stage_overlap": ("two HIP streams: dense sweeps + OneGNN of step k+1 beside the solver of step k"
                                   if overlap else "none (stages back to back on one stream)"),
                 "solver_threads_hint": args.threads_hint,
-                "solver_search": os.environ.get("LAPWARM_SEARCH", "legacy"),
                 "solver_helper_workgroups": helpers,
                 "branches": branches,
                 "ret_nonzero": int((ret != 0).sum()),

@@ -524,4 +524,35 @@ struct BlockCtx {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// Direct-to-LDS row request (LDS-DMA, global_load_lds_dwordx4): every lane names its own 16 source
+// bytes, the 64 x 16 bytes of a wave land contiguously at a wave-uniform LDS address (M0) + lane*16
+// -- no vector register is a destination, so nothing the compiler does with registers can meet a
+// load in flight.  The compiler does not count these loads: completion is waited for by hand with
+// s_waitcnt vmcnt(N), N = the requests issued AFTER the one that must have landed (vmcnt retires in
+// order; extra compiler loads or spills issued in between only make the wait longer, never shorter).
+// M0 is written in the same statement that reads it (cdna_hip_programming.md, section 5.7).
+__device__ __forceinline__ void dma_request16(const double *gsrc_lane, unsigned lds_dst_uniform)
+{
+    unsigned keep;
+    // (readfirstlane: the "s" operand must be in a scalar register whatever the compiler can prove)
+    lds_dst_uniform = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst_uniform);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc_lane), "s"(lds_dst_uniform)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void dma_wait()
+{
+    static_assert(N == 0, "only the full drain is used");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// LDS byte address of a pointer into the workgroup's LDS block
+__device__ __forceinline__ unsigned lds_address(const void *p)
+{
+    typedef __attribute__((address_space(3))) const unsigned char *lds_cptr;
+    return (unsigned)(unsigned long long)(lds_cptr)p;
+}
+
 }  // namespace lapwarm

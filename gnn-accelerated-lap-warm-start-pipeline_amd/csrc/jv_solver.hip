@@ -39,7 +39,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "cols_search.hpp"
 #include "device_utils.hpp"
 #include "jv_solver.hpp"
 
@@ -114,23 +113,15 @@ __device__ __forceinline__ unsigned long long stamp_now()
 
 template <int CH, int LDSL, int TB>
 struct Solver {
+    // LDS levels: 2 = all solver state in LDS, 1 = x and the free-row list in global memory,
+    // 0 = all state in global memory, 8 = as 0 with the head rows staged in LDS (below)
     static constexpr bool LDS_STATE = LDSL > 0 && LDSL != 8;
-    static constexpr bool COLS = LDSL >= 3 && LDSL <= 5;  // column-owned search (labels never move between threads)
-    static constexpr bool VEC2 = LDSL == 4 || LDSL == 5;  // ... with column pairs per thread (16-byte row loads; n even)
-    // level 6 = level 2 (position-owned search, all state in LDS) + the row of the NEXT queued head
-    // requested one step ahead straight into one of two LDS slots (LDS-DMA); the gathers of a
-    // prefetched step then read LDS instead of HBM
-    static constexpr bool PF = LDSL == 6 || LDSL == 8;
     // level 8 (rows longer than the CU's L1 can hold, n > 4,427): solver state in global memory as
     // level 0, but EVERY head row is brought into an LDS slot by coalesced LDS-DMA requests and
     // gathered from there -- the position-owned gather C[i][order[k]] touches a random 128-byte line
     // per lane, and a 64-128 KiB row thrashes the 32-KiB L1 (each line re-fetched up to CH times)
     static constexpr bool ROWLDS = LDSL == 8;
-#ifdef LAPWARM_L5_NODMA  // diagnostic: level-5 storage with the register prefetch of level 4
-    static constexpr bool DMA = false;
-#else
-    static constexpr bool DMA = LDSL == 5;    // ... and direct-to-LDS row requests two steps ahead (x, free list in global memory)
-#endif
+    static constexpr bool PF = ROWLDS;  // ... and the next queued head's row requested one step ahead
     static constexpr int kCacheLimit = (TB <= 256) ? 16 : ((TB <= 512) ? 32 : 4);  // positions per thread whose duals fit in registers
     static constexpr int kCacheLimitY = (TB <= 256) ? 16 : 2;
     // problem
@@ -139,11 +130,9 @@ struct Solver {
     // state
     double *dist, *v;
     int *order, *pred, *y, *x, *fr;
-    cols::Layout clay;  // column-owned search (levels 3-5): cols_search.hpp
-    cols::Ctl *cctl;
     int *ring;     // helper experiment: ring of upcoming head rows (null: off)
     int ring_count;
-    unsigned char *slots;  // levels 6, 8: row slots of slot_bytes each
+    unsigned char *slots;  // level 8: row slots of slot_bytes each
     int slot_bytes;
     int nslots;
     uint32_t *evt, *sbits, *used;
@@ -220,7 +209,7 @@ struct Solver {
     //     moved B on); hops only go up, so every slot is resolved independently.
     // Both parts are data-parallel over the lanes of wave 0.  A tie BEFORE the last strict event
     // (rare) takes the serial loop.
-    __device__ __forceinline__ void replay_find(int lo, double level_in)
+    __device__ __forceinline__ void replay_find(int lo)
     {
         const int lane = bc.lane;
         // ---- 1. ordered event list: evl[i] = position | strict << 31
@@ -356,9 +345,7 @@ struct Solver {
         }
         const int target = (best >= 0) ? order[best] : -1;
         const int head_j = order[lo];
-        // position-owned search: dist[] is indexed by column; column-owned search: dist[] holds the
-        // distances in POSITION order and the caller passes the level (the collection's minimum)
-        const double level = COLS ? level_in : dist[head_j];
+        const double level = dist[head_j];
         const int head_i = y[head_j];
         if (lane == 0) {
             ctrl->hi = hi;
@@ -478,7 +465,7 @@ struct Solver {
 #ifdef LAPWARM_DIAG_BARRIER
         int diag_prev_cnt = -1;
 #endif
-        bool pf_have = false;  // level 6: the current head's row sits in slot pf_slot
+        bool pf_have = false;  // level 8: the current head's row sits in slot pf_slot
         int pf_slot = 0;
         double level = 0.0;
         int guard = 0;
@@ -627,7 +614,7 @@ struct Solver {
                         if (sb) atomicOr(&sbits[wordi], sb << shift);
                     }
                     __syncthreads();
-                    if (bc.wave == 0) replay_find(lo, 0.0);
+                    if (bc.wave == 0) replay_find(lo);
                     __syncthreads();
                     hi = uni(ctrl->hi);
                     target = uni(ctrl->target);
@@ -676,15 +663,15 @@ struct Solver {
                 if (!from_slot) {
                     // not requested ahead: request it now, wait, and let one barrier publish it
                     pf_slot = 0;
-                    const unsigned sbase = cols::lds_address(slots) + (unsigned)bc.wave * 1024u;
+                    const unsigned sbase = lds_address(slots) + (unsigned)bc.wave * 1024u;
                     const int nt = (int)blockDim.x;
 #pragma unroll
                     for (int q = 0; q < CH / 2; ++q) {
                         int col = q * 2 * nt + 2 * bc.tid;
                         col = (col < n - 2) ? col : n - 2;
-                        cols::dma_request16(row + col, sbase + (unsigned)q * (unsigned)nt * 16u);
+                        dma_request16(row + col, sbase + (unsigned)q * (unsigned)nt * 16u);
                     }
-                    cols::dma_wait<0>();
+                    dma_wait<0>();
                     __syncthreads();
                     from_slot = true;
                 }
@@ -756,7 +743,7 @@ struct Solver {
                 if (queued && (unsigned)ri < (unsigned)n && nslots > 1) {
                     pf_next_slot = from_slot ? (pf_slot ^ 1) : 0;
                     const double *nrow = C + (size_t)ri * n;
-                    const unsigned sbase = cols::lds_address(slots) + (unsigned)pf_next_slot * (unsigned)slot_bytes +
+                    const unsigned sbase = lds_address(slots) + (unsigned)pf_next_slot * (unsigned)slot_bytes +
                                            (unsigned)bc.wave * 1024u;
                     const int nt = (int)blockDim.x;
 #pragma unroll
@@ -765,7 +752,7 @@ struct Solver {
                         // padding beyond n is never read)
                         int col = q * 2 * nt + 2 * bc.tid;
                         col = (col < n - 2) ? col : n - 2;
-                        cols::dma_request16(nrow + col, sbase + (unsigned)q * (unsigned)nt * 16u);
+                        dma_request16(nrow + col, sbase + (unsigned)q * (unsigned)nt * 16u);
                     }
                     pf_issued = true;
                 }
@@ -895,7 +882,7 @@ struct Solver {
             if constexpr (PF) {
                 // every wave's pieces of the requested row have landed before the barrier releases
                 // the readers of the next step
-                if (pf_issued) cols::dma_wait<0>();
+                if (pf_issued) dma_wait<0>();
                 pf_have = pf_issued;
                 pf_slot = pf_next_slot;
             }
@@ -1185,17 +1172,7 @@ struct Solver {
                 break;
             }
             if (f + 1 < n_free) ring_push(uni(fr[f + 1]));  // the helper fetches it while this path runs
-            int target;
-            if constexpr (COLS) {
-                // ends with a barrier (pred[] is dumped at the end)
-                target = uni(cols::search_path<CH, VEC2, TB, DMA>(clay, start));
-                if (target < 0) {
-                    err = uni(cctl->err);
-                    if (!err) err = 2;
-                }
-            } else {
-                target = find_path(start);
-            }
+            const int target = find_path(start);
             if (err) break;
             if (bc.tid == 0) {
                 // a corrupted chain must end in a return code, never in an out-of-range access
@@ -1583,7 +1560,7 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         int *ring = p.pf_ring + (size_t)hb * kRingInts;
         const double *Cb = p.C + (size_t)hb * n * n;
         const int lane = threadIdx.x;
-        const unsigned dummy = cols::lds_address(smem);
+        const unsigned dummy = lds_address(smem);
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
         int seen = 0;
         const int pieces = (n * 8 + 1023) / 1024;
@@ -1598,7 +1575,7 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
                     for (int k = hsel; k < pieces; k += p.helper) {
                         int col = k * 128 + lane * 2;
                         col = (col < n - 2) ? col : n - 2;
-                        cols::dma_request16(r + col, dummy);
+                        dma_request16(r + col, dummy);
                     }
                 }
                 ++seen;
@@ -1613,7 +1590,7 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
             if (__builtin_amdgcn_s_memrealtime() - t0 > (n <= 4096 ? 50000000ull : 6000000000ull)) break;  // 0.5 s / 60 s
             __builtin_amdgcn_s_sleep(1);
         }
-        cols::dma_wait<0>();
+        dma_wait<0>();
         return;
     }
     const int b = blockIdx.x;
@@ -1622,23 +1599,12 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
 
     Solver<CH, LDSL, TB> s;
     unsigned char *cur = smem;
-    if constexpr (LDSL == 5) {
-        // the three row slots of the direct-to-LDS requests come first; the third one doubles as
-        // the scratch arrays of the tie replay (evl, tmpcol: 8n + 8 bytes)
-        const int slot_bytes = (int)blockDim.x * CH * (int)sizeof(double);
-        s.clay.slots = 0;
-        s.clay.slot_bytes = slot_bytes;
-        cur += 3 * (size_t)slot_bytes + 16;
-    } else {
-        s.clay.slots = 0;
-        s.clay.slot_bytes = 0;
-    }
     s.slots = smem;
     s.slot_bytes = 0;
     s.nslots = 0;
-    if constexpr (LDSL == 6 || LDSL == 8) {
+    if constexpr (LDSL == 8) {
         s.slot_bytes = (int)blockDim.x * CH * (int)sizeof(double);
-        s.nslots = (LDSL == 6) ? 2 : solver_row_slots(n, CH);
+        s.nslots = solver_row_slots(n, CH);
         cur += (size_t)s.nslots * (size_t)s.slot_bytes + 16;
     }
     BlockExchange *ex = reinterpret_cast<BlockExchange *>(cur);
@@ -1654,11 +1620,7 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
     s.evb = reinterpret_cast<uint32_t *>(cur);
     cur += sizeof(uint32_t) * Wpad * 2;
     s.Wpad = Wpad;
-    if constexpr (LDSL == 5) {
-        const size_t slot_bytes = (size_t)blockDim.x * CH * sizeof(double);
-        s.evl = reinterpret_cast<int *>(smem + 2 * slot_bytes);
-        s.tmpcol = s.evl + n;
-    } else if constexpr (LDSL > 0 && LDSL != 8) {
+    if constexpr (LDSL > 0 && LDSL != 8) {
         s.evl = reinterpret_cast<int *>(cur);
         cur += sizeof(int) * n;
         s.tmpcol = reinterpret_cast<int *>(cur);
@@ -1666,17 +1628,6 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
     } else {
         s.evl = p.g_evl + (size_t)b * n;
         s.tmpcol = p.g_tmpcol + (size_t)b * (n + 2);
-    }
-    if constexpr (Solver<CH, LDSL, TB>::COLS) {
-        cur = smem + ((size_t)(cur - smem) + 15) / 16 * 16;
-        s.cctl = reinterpret_cast<cols::Ctl *>(cur);
-        s.clay.ctl = (int)(cur - smem);
-        cur += sizeof(cols::Ctl);
-        s.clay.qdesc = (int)(cur - smem);
-        cur += sizeof(cols::QDesc) * n;
-        s.clay.pos = (int)(cur - smem);
-        cur += sizeof(int) * n;
-        cur = smem + ((size_t)(cur - smem) + 15) / 16 * 16;
     }
     if constexpr (LDSL > 0 && LDSL != 8) {
         s.dist = reinterpret_cast<double *>(cur);
@@ -1689,7 +1640,7 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         cur += sizeof(int) * n;
         s.y = reinterpret_cast<int *>(cur);
         cur += sizeof(int) * n;
-        if constexpr (LDSL > 1 && LDSL != 5) {
+        if constexpr (LDSL > 1) {
             s.x = reinterpret_cast<int *>(cur);
             cur += sizeof(int) * n;
             s.fr = reinterpret_cast<int *>(cur);
@@ -1712,24 +1663,6 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
     s.C = p.C + (size_t)b * n * n;
     s.n = n;
     s.W = W;
-    if constexpr (Solver<CH, LDSL, TB>::COLS) {
-        auto off = [&](const void *ptr) { return (int)(reinterpret_cast<const unsigned char *>(ptr) - smem); };
-        s.clay.C = s.C;
-        s.clay.n = n;
-        s.clay.W = W;
-        s.clay.Wpad = Wpad;
-        s.clay.dist = off(s.dist);
-        s.clay.v = off(s.v);
-        s.clay.order = off(s.order);
-        s.clay.pred = off(s.pred);
-        s.clay.y = off(s.y);
-        s.clay.evt = off(s.evt);
-        s.clay.sbits = off(s.sbits);
-        s.clay.evb = off(s.evb);
-        s.clay.evl = off(s.evl);
-        s.clay.tmpcol = off(s.tmpcol);
-        s.clay.ex = off(ex);
-    }
     s.ring = (p.helper && p.pf_ring) ? p.pf_ring + (size_t)b * kRingInts : nullptr;
     s.ring_count = 0;
     s.scan_elems = s.init_elems = s.colred_elems = 0;
@@ -1758,9 +1691,6 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         return;
     }
 
-    if constexpr (Solver<CH, LDSL, TB>::COLS) {
-        if (tid == 0) cols::ctl_init(s.cctl);
-    }
     if (tid == 0) {
         s.ctrl->tie_find = 0;
         s.ctrl->ev_total[0] = 0;
@@ -1850,19 +1780,11 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
             st[1] = tight_total;
             st[2] = (branch == kBranchFallback || branch == kBranchCold) ? nf : free_after_greedy;
             st[3] = s.arr_fired;
-            if constexpr (Solver<CH, LDSL, TB>::COLS) {  // the column-owned search keeps its counters in LDS
-                st[4] = s.cctl->paths;
-                st[5] = s.cctl->finds;
-                st[6] = s.cctl->scan_steps;
-                st[7] = s.cctl->scan_elems;
-                st[8] = s.cctl->init_elems;
-            } else {
-                st[4] = s.paths;
-                st[5] = s.finds;
-                st[6] = s.scan_steps;
-                st[7] = s.scan_elems;
-                st[8] = s.init_elems;
-            }
+            st[4] = s.paths;
+            st[5] = s.finds;
+            st[6] = s.scan_steps;
+            st[7] = s.scan_elems;
+            st[8] = s.init_elems;
             st[9] = s.colred_elems;
             st[10] = s.transfer_rows;
             st[11] = s.arr_iters;
@@ -1872,15 +1794,8 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
             st[14] = (long long)(t_serial - t_start);  // greedy + micro-ARR part (SSP branch)
             st[15] = 0;
             for (int q = 16; q < kStatsPerInstance; ++q) st[q] = 0;
-#if defined(LAPWARM_STAMPS) || defined(LAPWARM_DMA_CHECK)
-            if constexpr (Solver<CH, LDSL, TB>::COLS) {
-                for (int q = 0; q < 16; ++q) st[16 + q] = s.cctl->stamps[q];
-            }
-#endif
 #ifdef LAPWARM_STAMPS
-            if constexpr (!Solver<CH, LDSL, TB>::COLS) {
-                for (int q = 0; q < 16; ++q) st[16 + q] = s.stamps[q];
-            }
+            for (int q = 0; q < 16; ++q) st[16 + q] = s.stamps[q];
 #endif
         }
     }
@@ -1900,10 +1815,8 @@ hipError_t launch_one(const SolverParams &p, int threads, size_t lds_bytes, hipS
 
 }  // namespace
 
-// level 4: as 3 with column pairs per thread (n even); level 3: column-owned search, every
-// array in LDS plus pos[] and the SCAN-list entries;
-// 2: position-owned search, every array in LDS; 1: x and the free-row list in global memory;
-// 0: all global
+// LDS levels: 2 = position-owned search, every array in LDS; 1 = x and the free-row list in global
+// memory; 0 = all global; 8 = all global + head rows staged in LDS row slots.
 // row slots of level 8: two (the next queued head's row is requested one step ahead) when they
 // fit beside the control blocks, else one, else none
 __host__ __device__ int solver_row_slots(int n, int ch)
@@ -1940,51 +1853,11 @@ size_t solver_lds_bytes(int n, int ch, int level)
     }
     if (level >= 1) bytes += (size_t)n * (2 * sizeof(double) + 5 * sizeof(int)) + 2 * sizeof(int);
     if (level >= 2) bytes += (size_t)n * 2 * sizeof(int);
-    if (level == 6) {
-        // level 2 plus two row slots of the padded row length
-        const size_t padded = ((size_t)n + (size_t)ch * 64 - 1) / ((size_t)ch * 64) * ((size_t)ch * 64);
-        return bytes + 2 * padded * sizeof(double) + 16;
-    }
-    if (level >= 3) bytes += sizeof(cols::Ctl) + (size_t)n * (sizeof(cols::QDesc) + sizeof(int)) + 32;  // + alignment slack
-    if (level == 5) {
-        // x and the free-row list live in global memory; three row slots of (padded) row length,
-        // the third one shared with evl / tmpcol
-        bytes -= (size_t)n * 2 * sizeof(int);
-        bytes -= (size_t)n * 2 * sizeof(int) + 2 * sizeof(int);
-        const size_t padded = ((size_t)n + (size_t)ch * 64 - 1) / ((size_t)ch * 64) * ((size_t)ch * 64);
-        bytes += 3 * padded * sizeof(double) + 16;
-    }
     return bytes;
-}
-
-// Which shortest-path search runs (LAPWARM_SEARCH): "legacy" (default) = position-owned search of
-// round 1; "cols" = column-owned search (cols_search.hpp), rows requested one step ahead into
-// registers; "dma" = column-owned with direct-to-LDS row requests two steps ahead.  All three are
-// bit-exact; measured on K3 (round 2, profiles/r02_search_variants.txt) the position-owned search
-// is still the fastest, so it stays the default and the other two are kept selectable.
-static int search_mode()
-{
-    static const int mode = [] {
-        const char *e = getenv("LAPWARM_SEARCH");
-        if (e && strcmp(e, "cols") == 0) return 1;
-        if (e && strcmp(e, "nodma") == 0) return 1;
-        if (e && strcmp(e, "dma") == 0) return 2;
-        if (e && strcmp(e, "pf") == 0) return 3;
-        return 0;
-    }();
-    return mode;
 }
 
 int solver_lds_level(int n, int ch)
 {
-    if (search_mode() == 3) {
-        if (n % 2 == 0 && ch >= 2 && solver_lds_bytes(n, ch, 6) <= kLdsBudgetBytes) return 6;
-    } else if (search_mode() != 0) {
-        // 5 = 4 with direct-to-LDS row requests two steps ahead (needs the global workspace for
-        // x and the free-row list); 4 = 3 with column pairs (16-byte row loads)
-        if (search_mode() == 2 && n % 2 == 0 && ch >= 2 && solver_lds_bytes(n, ch, 5) <= kLdsBudgetBytes) return 5;
-        if (solver_lds_bytes(n, ch, 3) <= kLdsBudgetBytes) return (n % 2 == 0 && ch >= 2) ? 4 : 3;
-    }
     if (solver_lds_bytes(n, ch, 2) <= kLdsBudgetBytes) return 2;
     if (solver_lds_bytes(n, ch, 1) <= kLdsBudgetBytes) return 1;
     return 0;
@@ -2057,30 +1930,16 @@ hipError_t launch_solver(const SolverParams &p_in, int threads_hint, hipStream_t
         const size_t lds8 = solver_lds_bytes(p.n, ch, 8);
         return launch_one<16, 8, 512>(p, threads, lds8, stream);
     }
-    int level = solver_lds_level(p.n, ch);
-    if (level == 5 && (long long)threads * ch != (((long long)p.n + ch * 64 - 1) / (ch * 64)) * (ch * 64))
-        level = 4;  // the row slots are sized for threads * ch == the padded row length
-    if (level == 6 && (long long)threads * ch != (((long long)p.n + ch * 64 - 1) / (ch * 64)) * (ch * 64))
-        level = 2;
-    if (level == 8 && (long long)threads * ch != (((long long)p.n + ch * 64 - 1) / (ch * 64)) * (ch * 64))
-        level = 0;
-    if ((level < 2 || level == 5 || level == 8) && !p.g_x) return hipErrorInvalidValue;
+    const int level = solver_lds_level(p.n, ch);
+    if (level < 2 && !p.g_x) return hipErrorInvalidValue;
     const size_t lds = solver_lds_bytes(p.n, ch, level);
 #define LAPWARM_CASE(CHV)                                                               \
     case CHV:                                                                           \
         if (threads <= 256) {                                                           \
-            if (level == 6) return launch_one<(CHV >= 2 ? CHV : 2), 6, 256>(p, threads, lds, stream); \
-            if (level == 5) return launch_one<(CHV >= 2 ? CHV : 2), 5, 256>(p, threads, lds, stream); \
-            if (level == 4) return launch_one<(CHV >= 2 ? CHV : 2), 4, 256>(p, threads, lds, stream); \
-            if (level == 3) return launch_one<CHV, 3, 256>(p, threads, lds, stream);    \
             if (level == 2) return launch_one<CHV, 2, 256>(p, threads, lds, stream);    \
             if (level == 1) return launch_one<CHV, 1, 256>(p, threads, lds, stream);    \
             return launch_one<CHV, 0, 256>(p, threads, lds, stream);                    \
         }                                                                               \
-        if (level == 6) return launch_one<(CHV >= 2 ? CHV : 2), 6, 1024>(p, threads, lds, stream); \
-        if (level == 5) return launch_one<(CHV >= 2 ? CHV : 2), 5, 1024>(p, threads, lds, stream); \
-        if (level == 4) return launch_one<(CHV >= 2 ? CHV : 2), 4, 1024>(p, threads, lds, stream); \
-        if (level == 3) return launch_one<CHV, 3, 1024>(p, threads, lds, stream);       \
         if (level == 2) return launch_one<CHV, 2, 1024>(p, threads, lds, stream);       \
         if (level == 1) return launch_one<CHV, 1, 1024>(p, threads, lds, stream);       \
         return launch_one<CHV, 0, 1024>(p, threads, lds, stream);
@@ -2098,11 +1957,12 @@ hipError_t launch_solver(const SolverParams &p_in, int threads_hint, hipStream_t
 bool solver_needs_global_state(int n)
 {
     // a threads_hint may pick another CH: be conservative for every supported geometry.
-    // Levels 2, 3, 4 and 6 keep everything in LDS; 0, 1, 5 and 8 use the global workspace.
+    // Level 2 keeps everything in LDS; 0, 1 and 8 use the global workspace.
     for (int c = 1; c <= 16; c <<= 1) {
-        const int l = solver_lds_level(n, c);
-        if (l < 2 || l == 5 || l == 8) return true;
+        if (solver_lds_level(n, c) < 2) return true;
     }
+    int t, c;
+    if (large_row_geometry(n, &t, &c)) return true;
     return false;
 }
 
