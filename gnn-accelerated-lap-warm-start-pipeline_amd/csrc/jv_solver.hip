@@ -1163,9 +1163,9 @@ struct Solver {
     }
 
     // lapjv.cpp:286-319: one path per free row, in list order.
-    __device__ __forceinline__ void augment_all(int n_free)
+    __device__ __forceinline__ void augment_all(int f_first, int n_free)
     {
-        for (int f = 0; f < n_free && !err; ++f) {
+        for (int f = f_first; f < n_free && !err; ++f) {
             const int start = uni(fr[f]);
             if ((unsigned)start >= (unsigned)n) {
                 err = 2;
@@ -1683,6 +1683,10 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         if (tid == 0) {
             if (p.helper && p.pf_ring)
                 __hip_atomic_store(&p.pf_ring[(size_t)b * kRingInts], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.phase == 1) {  // nothing for the cooperative kernel to do; phase 2 comes through here again
+                for (int q = 0; q < kHandInts; ++q) p.hand[(size_t)b * kHandInts + q] = 0;
+                return;
+            }
             p.ret[b] = -3;
             if (p.stats) {
                 for (int q = 0; q < kStatsPerInstance; ++q) p.stats[(size_t)b * kStatsPerInstance + q] = 0;
@@ -1711,21 +1715,58 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         s.evb[w] = 0;
         s.evb[Wpad + w] = 0;
     }
-    int tight_local = 0;
-    for (int j = tid; j < n; j += blockDim.x) {
-        s.x[j] = -1;
-        s.y[j] = -1;
-        if (p.mode == kModeSeeded) {
-            s.v[j] = p.v_work[(size_t)b * n + j];
-            tight_local += p.tight_cnt[(size_t)b * n + j];
-        }
-    }
     long long branch = kBranchCold;
     long long tight_total = 0;
     long long free_after_greedy = 0;
     int nf = 0;
+    if (p.phase == 2) {
+        // ---- resume behind the cooperative kernel: x, y, v and the free rows come back from the
+        // global state arrays, the rows hand[1] .. hand[0] are still to be augmented
+        const size_t o = (size_t)b * n;
+        const int *hand = p.hand + (size_t)b * kHandInts;
+        nf = hand[0];
+        const int f0 = hand[1];
+        for (int j = tid; j < n; j += blockDim.x) {
+            if (s.x != p.g_x + o) s.x[j] = p.g_x[o + j];
+            if (s.y != p.g_y + o) s.y[j] = p.g_y[o + j];
+            if (s.v != p.g_v + o) s.v[j] = p.g_v[o + j];
+            if (s.fr != p.g_fr + o && j < nf) s.fr[j] = p.g_fr[o + j];
+        }
+        branch = hand[5];
+        tight_total = hand[6];
+        free_after_greedy = hand[7];
+        s.arr_fired = hand[8];
+        s.transfer_rows = hand[9];
+        s.arr_iters = hand[10];
+        s.colred_elems = ((long long)hand[12] << 32) | (unsigned)hand[11];
+        s.err = hand[13];
+        if (hand[2] | hand[4]) s.err = 30 + ((hand[2] | hand[4]) & 31);  // the cooperative kernel failed
+        __syncthreads();
+        if (!s.err && f0 >= 0 && f0 < nf) s.augment_all(f0, nf);
+        if (p.cstats) {
+            const long long *cs = p.cstats + (size_t)b * kCoopStats;
+            s.paths += (int)cs[0];
+            s.finds += (int)cs[1];
+            s.scan_steps += (int)cs[2];
+            s.scan_elems += cs[3];
+            s.init_elems += cs[4];
+        }
+    }
+    int tight_local = 0;
+    if (p.phase != 2) {
+        for (int j = tid; j < n; j += blockDim.x) {
+            s.x[j] = -1;
+            s.y[j] = -1;
+            if (p.mode == kModeSeeded) {
+                s.v[j] = p.v_work[(size_t)b * n + j];
+                tight_local += p.tight_cnt[(size_t)b * n + j];
+            }
+        }
+    }
     bool cold = (p.mode != kModeSeeded);
-    if (p.mode == kModeSeeded) {
+    if (p.phase == 2) {
+        // (everything below up to the outputs belongs to phases 0 and 1)
+    } else if (p.mode == kModeSeeded) {
         const int tt = s.bc.sum_i32(tight_local);  // includes the barrier that publishes the init
         tight_total = tt;
         cold = (double)tt < 1.2 * n;  // quality gate, lapjv_seeded.cpp:116
@@ -1734,7 +1775,8 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         __syncthreads();
     }
     bool run_paths = false;
-    if (cold) {
+    if (p.phase == 2) {
+    } else if (cold) {
         nf = s.cold_prepare();
         free_after_greedy = nf;
         run_paths = nf > 0;
@@ -1752,7 +1794,42 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
             run_paths = true;
         }
     }
-    if (run_paths && !s.err) s.augment_all(nf);
+    if (p.phase == 1) {
+        // ---- hand over to the cooperative kernel: state to the global arrays, mailbox zeroed
+        __syncthreads();
+        const size_t o = (size_t)b * n;
+        for (int j = tid; j < n; j += blockDim.x) {
+            if (s.x != p.g_x + o) p.g_x[o + j] = s.x[j];
+            if (s.y != p.g_y + o) p.g_y[o + j] = s.y[j];
+            if (s.v != p.g_v + o) p.g_v[o + j] = s.v[j];
+            if (s.fr != p.g_fr + o && j < nf) p.g_fr[o + j] = s.fr[j];
+        }
+        const size_t ng = (size_t)p.mail_granules;
+        for (size_t q = tid; q < ng; q += blockDim.x) p.mail[(size_t)b * ng + q] = 0ull;
+        if (tid == 0) {
+            int *hand = p.hand + (size_t)b * kHandInts;
+            const int e1 = s.err | s.ctrl->err;
+            hand[0] = (run_paths && !e1) ? nf : 0;
+            hand[1] = 0;
+            hand[2] = 0;
+            hand[3] = 0;
+            hand[4] = 0;
+            hand[5] = (int)branch;
+            hand[6] = (int)tight_total;
+            hand[7] = (int)free_after_greedy;
+            hand[8] = s.arr_fired;
+            hand[9] = s.transfer_rows;
+            hand[10] = s.arr_iters;
+            hand[11] = (int)(s.colred_elems & 0xffffffffLL);
+            hand[12] = (int)(s.colred_elems >> 32);
+            hand[13] = e1;
+            if (p.cstats) {
+                for (int q = 0; q < kCoopStats; ++q) p.cstats[(size_t)b * kCoopStats + q] = 0;
+            }
+        }
+        return;
+    }
+    if (p.phase == 0 && run_paths && !s.err) s.augment_all(0, nf);
     __syncthreads();
     const int err = s.err | s.ctrl->err;
     for (int j = tid; j < n; j += blockDim.x) {
@@ -1792,8 +1869,12 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
             const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
             st[13] = (long long)(t_end - t_start);     // whole kernel, 10 ns ticks
             st[14] = (long long)(t_serial - t_start);  // greedy + micro-ARR part (SSP branch)
-            st[15] = 0;
+            // paths the cooperative kernel completed | why it stopped early << 32 (-1: not used)
+            st[15] = (p.phase == 2) ? ((long long)p.hand[(size_t)b * kHandInts + 1] |
+                                       ((long long)p.hand[(size_t)b * kHandInts + 3] << 32))
+                                    : -1;
             for (int q = 16; q < kStatsPerInstance; ++q) st[q] = 0;
+            if (p.phase == 2 && p.cstats) st[16] = p.cstats[(size_t)b * kCoopStats + 5];  // exchange rounds
 #ifdef LAPWARM_STAMPS
             for (int q = 0; q < 16; ++q) st[16 + q] = s.stamps[q];
 #endif
@@ -1903,7 +1984,45 @@ bool solver_uses_helpers(int n)
     return want && n >= 1024 && n <= max_n && n % 2 == 0;
 }
 
+static hipError_t launch_phase(const SolverParams &p_in, int threads_hint, hipStream_t stream);
+
+// The whole solve: one launch of jv_instance_kernel, or -- where the cooperative shortest-path phase
+// is enabled for this size (coop_ssp.hip) -- three: phase 1 (greedy / micro-ARR / cold preparation),
+// the cooperative kernel, phase 2 (whatever it left + the outputs).
 hipError_t launch_solver(const SolverParams &p_in, int threads_hint, hipStream_t stream)
+{
+    if (!(coop_enabled(p_in.n) && p_in.hand && p_in.mail && p_in.cstats && p_in.g_x)) {
+        SolverParams p = p_in;
+        p.phase = 0;
+        return launch_phase(p, threads_hint, stream);
+    }
+    SolverParams p = p_in;
+    p.phase = 1;
+    p.mail_granules = (int)coop_mail_granules(p.n);
+    hipError_t e = launch_phase(p, threads_hint, stream);
+    if (e != hipSuccess) return e;
+    CoopParams c;
+    c.C = p.C;
+    c.n = p.n;
+    c.batch = p.batch;
+    c.G = 0;
+    c.first = 0;
+    c.count = p.batch;
+    c.v = p.g_v;
+    c.x = p.g_x;
+    c.y = p.g_y;
+    c.pred = p.g_pred;
+    c.fr = p.g_fr;
+    c.hand = p.hand;
+    c.cstats = p.cstats;
+    c.mail = p.mail;
+    e = launch_coop(c, stream);
+    if (e != hipSuccess) return e;
+    p.phase = 2;
+    return launch_phase(p, threads_hint, stream);
+}
+
+static hipError_t launch_phase(const SolverParams &p_in, int threads_hint, hipStream_t stream)
 {
     SolverParams p = p_in;
     static const int n_helpers = [] {
@@ -1913,7 +2032,8 @@ hipError_t launch_solver(const SolverParams &p_in, int threads_hint, hipStream_t
     }();
     // (a helper can only help while its solver runs: with more workgroups than CUs the helpers would
     // be dispatched after the solvers they serve and leave at once -- skip them)
-    p.helper = (p.mode == kModeSeeded && p.pf_ring && solver_uses_helpers(p.n) && p.batch * (1 + n_helpers) <= 256)
+    p.helper = (p.phase == 0 && p.mode == kModeSeeded && p.pf_ring && solver_uses_helpers(p.n) &&
+                p.batch * (1 + n_helpers) <= 256)
                    ? n_helpers
                    : 0;
     int threads, ch;

@@ -46,9 +46,42 @@ struct SolverParams {
     // rows, zeroed by the caller; word 0 = done flag, words 2.. = (generation << 16 | row)
     int *pf_ring;
     int helper;
+    // cooperative shortest-path phase (coop_ssp.hip): phase 0 = the whole solve in this kernel;
+    // 1 = stop before the shortest-path phase and leave x, y, v, the free-row list in the global
+    // state arrays + hand[]; 2 = take x, y, v back, run the paths the cooperative kernel left
+    // (hand[1] .. hand[0]) and write the outputs
+    int phase;
+    int *hand;                 // [batch][kHandInts]
+    long long *cstats;         // [batch][kCoopStats] path counters of the cooperative kernel
+    unsigned long long *mail;  // [batch][coop_mail_granules(n)] zeroed by phase 1
+    int mail_granules;
 };
 constexpr int kRingSlots = 64;
 constexpr int kRingInts = 2 + kRingSlots;
+
+// hand[]: 0 free rows, 1 paths done by the cooperative kernel (resume index), 2 its error code,
+// 3 why it stopped early, 4 error seen by a member other than the leader, 5.. what phase 1 knows
+// and phase 2 reports (branch, tight edges, free rows after greedy, micro-ARR firings, transfer
+// rows, ARR iterations, column-reduction elements lo/hi, phase-1 error)
+constexpr int kHandInts = 16;
+constexpr int kCoopStats = 8;
+
+struct CoopParams {
+    const double *C;
+    int n, batch;
+    int G;             // members (single-wave workgroups) per instance, filled in by launch_coop
+    int first, count;  // instances [first, first + count) of this launch
+    double *v;         // [batch][n] column duals (the solver's global state arrays)
+    int *x, *y, *pred;
+    const int *fr;     // [batch][n] free rows, hand[0] of them
+    int *hand;
+    long long *cstats;
+    unsigned long long *mail;
+};
+bool coop_enabled(int n);
+int coop_members(int n);
+size_t coop_mail_granules(int n);
+hipError_t launch_coop(const CoopParams &p, hipStream_t stream);
 
 size_t solver_lds_bytes(int n, int ch, int level);
 int solver_lds_level(int n, int ch);

@@ -52,6 +52,9 @@ struct SeededWs {
     double *g_dist, *g_v;
     int *g_order, *g_pred, *g_y, *g_x, *g_fr, *g_evl, *g_tmpcol;
     int *pf_ring;
+    int *hand;
+    long long *cstats;
+    unsigned long long *mail;
     size_t bytes;
 };
 
@@ -69,7 +72,11 @@ SeededWs carve_seeded(void *ws, int batch, int n)
     s.flags = c.take<int>((size_t)batch);
     s.tight_bits = c.take<uint32_t>(bn * W);
     s.pf_ring = c.take<int>((size_t)batch * kRingInts);
-    if (solver_needs_global_state(n)) {
+    const bool coop = coop_enabled(n);
+    s.hand = coop ? c.take<int>((size_t)batch * kHandInts) : nullptr;
+    s.cstats = coop ? c.take<long long>((size_t)batch * kCoopStats) : nullptr;
+    s.mail = coop ? c.take<unsigned long long>((size_t)batch * coop_mail_granules(n)) : nullptr;
+    if (solver_needs_global_state(n) || coop) {
         s.g_dist = c.take<double>(bn);
         s.g_v = c.take<double>(bn);
         s.g_order = c.take<int>(bn);
@@ -263,6 +270,9 @@ int lapwarm_seeded_batched(const double *C, int batch, int n, const double *u_se
     sp.g_evl = w.g_evl;
     sp.g_tmpcol = w.g_tmpcol;
     sp.pf_ring = w.pf_ring;
+    sp.hand = w.hand;
+    sp.cstats = w.cstats;
+    sp.mail = w.mail;
     HIP_TRY(profile_begin(stream));
     HIP_TRY(launch_solver(sp, threads_hint, stream));
     HIP_TRY(profile_end(stream));
@@ -321,6 +331,9 @@ static int lapjv_batched_impl(const double *C, int batch, int n, int *x, int *y,
     sp.g_fr = w.g_fr;
     sp.g_evl = w.g_evl;
     sp.g_tmpcol = w.g_tmpcol;
+    sp.hand = w.hand;
+    sp.cstats = w.cstats;
+    sp.mail = w.mail;
     HIP_TRY(profile_begin(stream));
     HIP_TRY(launch_solver(sp, threads_hint, stream));
     HIP_TRY(profile_end(stream));

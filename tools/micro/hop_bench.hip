@@ -18,6 +18,10 @@ struct Params {
     const double *rows;        // row pool (rows_n rows of rowlen doubles) or null
     long long *out;            // [inst][G][2]: ticks (100 MHz), failures
     int G, K, rounds, same_xcd, rowlen, rows_n, ch, inst;
+    int store_mode;  // 0: agent-scope atomic store (sc1, write-through); 1: workgroup-scope atomic store (sc0: stays in
+                     // the XCD's L2 -- only meaningful when every member sits on one XCD); 2: plain volatile store
+    int sleep;       // s_sleep between polls
+    int *xcc;        // [inst][G] XCC id of each member
 };
 
 template <int CH>
@@ -42,6 +46,7 @@ __global__ void __launch_bounds__(64) hop_kernel(Params p)
     double facc = 0.0;
     int fails = 0;
     unsigned row = (unsigned)(b * 131 + g * 7) % (unsigned)p.rows_n;
+    if (lane == 0) p.xcc[b * p.G + g] = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf);
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     for (int r = 1; r <= p.rounds; ++r) {
         if (p.rows) {
@@ -56,7 +61,13 @@ __global__ void __launch_bounds__(64) hop_kernel(Params p)
         unsigned long long *buf = mail + (size_t)(r & 1) * GK;
         if (lane < p.K) {
             const unsigned val = (unsigned)(g * 1000 + lane) + (unsigned)r * 3u + (unsigned)(facc != 12345.0);
-            __hip_atomic_store((gu64 *)(buf + g * p.K + lane), ((unsigned long long)(unsigned)r << 32) | val, RLX_AGENT);
+            const unsigned long long w = ((unsigned long long)(unsigned)r << 32) | val;
+            if (p.store_mode == 0)
+                __hip_atomic_store((gu64 *)(buf + g * p.K + lane), w, RLX_AGENT);
+            else if (p.store_mode == 1)
+                __hip_atomic_store((gu64 *)(buf + g * p.K + lane), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else
+                *(volatile unsigned long long *)(buf + g * p.K + lane) = w;
         }
         unsigned long long got[4] = {0, 0, 0, 0};
         unsigned spins = 0;
@@ -71,7 +82,8 @@ __global__ void __launch_bounds__(64) hop_kernel(Params p)
                 }
             }
             if (__all(ok)) break;
-            if (++spins > (1u << 22)) {
+            if (p.sleep) __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 21)) {
                 fails++;
                 break;
             }
@@ -107,12 +119,15 @@ int main()
     double *rows;
     CK(hipMalloc(&rows, (size_t)rowlen * rows_n * 8));
     CK(hipMemset(rows, 0, (size_t)rowlen * rows_n * 8));
-    printf("inst G K same_xcd gather   us/round (max over members)  fails\n");
-    const int cfgs[][5] = {
-        // inst, G, K, same_xcd, gather(CH or 0)
-        {1, 2, 1, 1, 0},  {1, 2, 1, 0, 0},  {1, 8, 6, 1, 0},  {1, 8, 6, 0, 0},  {1, 16, 6, 1, 0}, {1, 16, 6, 0, 0},
-        {1, 32, 6, 1, 0}, {1, 32, 6, 0, 0}, {1, 16, 6, 1, 4}, {1, 32, 6, 1, 8}, {32, 8, 6, 1, 0}, {32, 8, 6, 1, 4},
-        {32, 16, 6, 1, 0}, {32, 16, 6, 1, 4}, {32, 16, 6, 0, 4}, {8, 32, 6, 1, 8},
+    printf("inst G K same_xcd gather store sleep   us/round (max over members)  fails  xcds\n");
+    const int cfgs[][7] = {
+        // inst, G, K, same_xcd, gather(CH or 0), store_mode, sleep
+        {1, 2, 1, 1, 0, 0, 0},  {1, 2, 1, 1, 0, 1, 0},  {1, 2, 1, 1, 0, 2, 0},  {1, 2, 1, 0, 0, 1, 0},
+        {1, 8, 6, 1, 0, 0, 0},  {1, 8, 6, 1, 0, 1, 0},  {1, 8, 6, 1, 0, 2, 0},  {1, 8, 6, 1, 0, 0, 1},
+        {1, 16, 6, 1, 0, 1, 0}, {1, 32, 6, 1, 0, 1, 0}, {1, 16, 6, 1, 4, 1, 0},
+        {32, 8, 6, 1, 0, 0, 0}, {32, 8, 6, 1, 0, 1, 0}, {32, 8, 6, 1, 4, 1, 0}, {32, 8, 6, 1, 4, 0, 1},
+        {32, 16, 6, 1, 0, 1, 0}, {32, 16, 6, 1, 4, 1, 0}, {32, 16, 6, 1, 4, 0, 1}, {8, 32, 6, 1, 8, 1, 0},
+        {32, 8, 6, 0, 4, 1, 0},
     };
     for (auto &c : cfgs) {
         Params p;
@@ -125,6 +140,9 @@ int main()
         p.rowlen = rowlen;
         p.rows_n = rows_n;
         p.rows = c[4] ? rows : nullptr;
+        p.store_mode = c[5];
+        p.sleep = c[6];
+        CK(hipMalloc(&p.xcc, (size_t)p.inst * p.G * 4));
         const size_t mail_bytes = (size_t)p.inst * 2 * p.G * p.K * 8;
         CK(hipMalloc(&p.mail, mail_bytes));
         CK(hipMemset(p.mail, 0, mail_bytes));
@@ -142,7 +160,18 @@ int main()
             if (out[i] > mx) mx = out[i];
             fails += out[i + 1];
         }
-        printf("%4d %2d %d %d %d   %.3f   %lld\n", p.inst, p.G, p.K, p.same_xcd, c[4], mx * 0.01 / rounds, fails);
+        std::vector<int> xcc((size_t)p.inst * p.G);
+        CK(hipMemcpy(xcc.data(), p.xcc, xcc.size() * 4, hipMemcpyDeviceToHost));
+        int mixed = 0;  // instances whose members do not share an XCD
+        for (int b = 0; b < p.inst; ++b)
+            for (int g = 1; g < p.G; ++g)
+                if (xcc[(size_t)b * p.G + g] != xcc[(size_t)b * p.G]) {
+                    ++mixed;
+                    break;
+                }
+        printf("%4d %2d %d %d %d %d %d   %.3f   %lld   mixed-XCD instances %d (inst0: %d %d)\n", p.inst, p.G, p.K, p.same_xcd, c[4],
+               c[5], c[6], mx * 0.01 / rounds, fails, mixed, xcc[0], xcc[p.G - 1]);
+        CK(hipFree(p.xcc));
         CK(hipFree(p.mail));
         CK(hipFree(p.out));
     }
