@@ -41,16 +41,26 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 #define LAPWARM_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-constexpr int kK = 6;      // granules per member record
-constexpr int kEmax = 3;   // tie events a member publishes per round (2 granules each)
+constexpr int kK = 4;      // granules per member record
+constexpr int kEmax = 2;   // tie events a member publishes per round (2 granules each)
 constexpr int kWin = 4;    // window: events applied per round = columns at order[hi .. hi+3] published per round
-constexpr int kWinGran = 4 * kWin;
+constexpr int kSlot = 6;   // granules per window slot: column | predecessor << 16, matched row + 1, distance, dual
+constexpr int kWinGran = kSlot * kWin;
 constexpr int kQ = 1024;   // replicated SCAN queue (entries: column, matched row)
+constexpr int kFL = 256;   // foreign-column list of a member (prefetch hint only: overflow just loses hints)
 constexpr unsigned kFlagBail = 1u, kFlagErr = 2u;
 
 __device__ __forceinline__ void st_gran(unsigned long long *g, unsigned tag, unsigned val)
 {
     __hip_atomic_store((gu64 *)g, ((unsigned long long)tag << 32) | val, LAPWARM_RLX_AGENT);
+}
+// Same granule, stored with WORKGROUP scope (sc0): the line stays in the XCD's L2 instead of being
+// written through to memory, and the agent-scope (sc1) polls of members ON THE SAME XCD are served
+// from that L2 (tools/micro/hop_bench.hip: 0.99 vs 1.22 us per 8-member round).  Never visible to
+// another XCD -- only used after every member of the instance has reported the same XCC id.
+__device__ __forceinline__ void st_gran_xcd(unsigned long long *g, unsigned tag, unsigned val)
+{
+    __hip_atomic_store((gu64 *)g, ((unsigned long long)tag << 32) | val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ unsigned long long ld_gran(const unsigned long long *g)
 {
@@ -76,6 +86,25 @@ __device__ __forceinline__ double mk_f64(unsigned lo, unsigned hi)
 
 enum { kRcGo = 0, kRcTarget = 1, kRcBail = 2, kRcErr = 3 };
 
+// diagnostic build (make coop-stamps): where a relax step's cycles go.  Never shipped or benchmarked.
+#ifdef LAPWARM_COOP_STAMPS
+__device__ __forceinline__ unsigned long long cstamp()
+{
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define CSTAMP(var) const unsigned long long var = cstamp()
+#define CSTAMP_ADD(slot, t1, t0) stamps[slot] += (long long)((t1) - (t0))
+#define CSTAMP_INC(slot) stamps[slot] += 1
+#define CSTAMP_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define CSTAMP(var)
+#define CSTAMP_ADD(slot, t1, t0)
+#define CSTAMP_INC(slot)
+#define CSTAMP_WAIT()
+#endif
+
 template <int CH, int NL>
 struct Member {
     static constexpr int P = 64 * CH;  // positions per member
@@ -86,8 +115,12 @@ struct Member {
     unsigned long long *mail;  // [2][NGtot]
     int G, g, lane, base, b0, NGm, NGtot;
     int2 *q;       // LDS: replicated SCAN queue
-    unsigned *rx;  // LDS: payloads of the round just polled
+    unsigned gv[NL];  // payloads of the round just polled: granule i sits in lane i % 64 of gv[i / 64]
     int2 *lj;      // LDS: (column, matched row) of this member's positions during a collection
+    unsigned *wb;  // LDS: [4][CH][kSlot] state of the (at most four) lanes that own positions hi .. hi+3
+    int *fl;       // LDS: columns from other members' ranges that sit at positions of this member
+    int nfl;       // (their cost entries are not covered by the range prefetch)
+    unsigned dummy_lds;  // LDS byte address of a 1-KiB area the prefetch requests land in (never read)
     int jr[CH], yr[CH], pr[CH];  // column at the position, its matched row, its predecessor row
     double vr[CH], dk[CH];       // its dual, its tentative distance
     int lo, hi, ready, head_i, head_j;
@@ -96,20 +129,65 @@ struct Member {
     long long scan_elems, init_elems;
     int paths, finds, scan_steps;
     int err, bail_reason;
+    bool same_xcd, allow_xcd_stores;
+#ifdef LAPWARM_COOP_STAMPS
+    long long stamps[10];
+#endif
 
     // ---------------------------------------------------------------- exchange
-    __device__ __forceinline__ void publish(unsigned w0, unsigned w1, unsigned w2, unsigned w3, unsigned w4, unsigned w5)
+    // ONE store instruction per round: lanes 0..3 carry this member's record, lanes 8..31 the window
+    // granules this member is the writer of (the owner of position hi + t; the last member for slots
+    // beyond position n-1).  Window values are staged in wb[] by the lanes that own the positions.
+    // (Separate store blocks per position made hipcc drain vmcnt before each of them: one write-through
+    // store latency per block, ~2,800 cycles per step -- profiles/r03_coop_stamps.txt.)
+    __device__ __forceinline__ void publish(unsigned w0, unsigned w1, unsigned w2, unsigned w3, bool with_window)
     {
         unsigned w = w0;
         w = (lane == 1) ? w1 : w;
         w = (lane == 2) ? w2 : w;
         w = (lane == 3) ? w3 : w;
-        w = (lane == 4) ? w4 : w;
-        w = (lane == 5) ? w5 : w;
-        if (lane < kK) st_gran(mail + (size_t)(seq & 1u) * NGtot + g * kK + lane, seq, w);
+        bool mine = lane < kK;
+        int idx = g * kK + lane;
+        if (with_window) {
+            const int wl = lane - 8;
+            if ((unsigned)wl < (unsigned)kWinGran) {
+                const int t = wl / kSlot, e = wl - t * kSlot;
+                const int pos = hi + t;
+                mine = (pos < n) ? ((unsigned)(pos - base) < (unsigned)P) : (g == G - 1);
+                // staged by lane (pos - base) / CH as its position (pos - base) % CH; stage row 0 is lane L0
+                const int lp = pos - base, L0 = (hi >= base) ? (hi - base) / CH : 0;
+                const bool owned = (pos < n) && ((unsigned)lp < (unsigned)P);
+                w = owned ? wb[((lp / CH - L0) * CH + lp % CH) * kSlot + e] : 0u;
+                idx = NGm + wl;
+            }
+        }
+        if (mine) {
+            if (same_xcd)
+                st_gran_xcd(mail + (size_t)(seq & 1u) * NGtot + idx, seq, w);
+            else
+                st_gran(mail + (size_t)(seq & 1u) * NGtot + idx, seq, w);
+        }
+    }
+    // First round of the launch: where does every member run?  (HW_REG_XCC_ID, bits 3:0.)  Dispatch
+    // deals workgroups to the XCDs round robin and the grid is laid out for it, but nothing promises
+    // that: the cheaper same-XCD stores are used only when the hardware says so.
+    __device__ __forceinline__ bool setup_round()
+    {
+        same_xcd = false;
+        const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;
+        ++seq;
+        publish(xcc | 0x100u, 0, 0, 0, false);
+        if (!poll(NGm)) {
+            err = 20;
+            return false;
+        }
+        unsigned other = xcc | 0x100u;
+        if (lane < G) other = member_word(0);
+        same_xcd = (__ballot(other != (xcc | 0x100u)) == 0ull) && allow_xcd_stores;
+        return true;
     }
     // Waits until the first `need` granules of this round's buffer carry this round's tag and
-    // leaves their payloads in rx[].  Bounded: ~2 s (a member that never arrives, e.g. because it
+    // leaves their payloads in gv[].  Bounded: ~2 s (a member that never arrives, e.g. because it
     // was never dispatched, must end in an error code, not in a hang).
     __device__ __forceinline__ bool poll(int need)
     {
@@ -131,28 +209,93 @@ struct Member {
             }
             if (__all(ok)) {
 #pragma unroll
-                for (int qd = 0; qd < NL; ++qd) {
-                    const int idx = qd * 64 + lane;
-                    if (idx < need) rx[idx] = val[qd];
-                }
+                for (int qd = 0; qd < NL; ++qd) gv[qd] = val[qd];
                 return true;
             }
             if ((++spins & 255u) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) return false;
         }
     }
-    __device__ __forceinline__ unsigned rxu(int idx) const { return (unsigned)uni((int)rx[idx]); }
+    // payload of granule idx (idx wave-uniform): a register read, no LDS round trip
+    __device__ __forceinline__ unsigned rxu(int idx) const
+    {
+        const int i = uni(idx);
+        if constexpr (NL == 1) {
+            return (unsigned)__builtin_amdgcn_readlane((int)gv[0], i);
+        } else if constexpr (NL == 2) {
+            return (i < 64) ? (unsigned)__builtin_amdgcn_readlane((int)gv[0], i)
+                            : (unsigned)__builtin_amdgcn_readlane((int)gv[1], i - 64);
+        } else {
+            if (i < 64) return (unsigned)__builtin_amdgcn_readlane((int)gv[0], i);
+            if (i < 128) return (unsigned)__builtin_amdgcn_readlane((int)gv[1], i - 64);
+            return (unsigned)__builtin_amdgcn_readlane((int)gv[NL - 1], i - 128);
+        }
+    }
+    // the records fill granules 0 .. G*kK-1: one register up to 16 members, two up to 32
+    static constexpr bool kWideRec = NL > 2;
+    // lane m < G: word `slot` of member m's record
+    __device__ __forceinline__ unsigned member_word(int slot) const
+    {
+        const int idx = lane * kK + slot;
+        const unsigned a = (unsigned)__shfl((int)gv[0], idx & 63, kWave);
+        if constexpr (kWideRec) {
+            const unsigned b = (unsigned)__shfl((int)gv[1], idx & 63, kWave);
+            return (idx < 64) ? a : b;
+        }
+        return a;
+    }
 
     // flags word of every member (granule `slot` of its record, bits `shift`..): any bail / error?
     __device__ __forceinline__ int check_flags(int slot, int shift)
     {
+        // (looked at on the lanes that hold that granule: no cross-lane traffic)
         unsigned f = 0;
-        if (lane < G) f = (rx[lane * kK + slot] >> shift) & 3u;
+        if constexpr (kWideRec) {
+            const unsigned w = member_word(slot);
+            if (lane < G) f = (w >> shift) & 3u;
+        } else {
+            if (lane < NGm && (lane & (kK - 1)) == slot) f = (gv[0] >> shift) & 3u;
+        }
         if (__ballot((f & kFlagErr) != 0)) {
             if (!err) err = 21;  // another member reported an error
             return kRcErr;
         }
         if (__ballot((f & kFlagBail) != 0)) return kRcBail;
         return kRcGo;
+    }
+
+    // ---------------------------------------------------------------- row prefetch towards the XCD's L2
+    // The next queued head's row is known one step ahead in most steps: request this member's piece
+    // of it (its own column range + the foreign columns it has adopted) by LDS-DMA into a dummy
+    // area -- no register is a destination, nothing ever waits for it on purpose, and the row gather
+    // of the next step then hits the L2 instead of HBM.  Issued after this step's row has arrived:
+    // vmcnt retires in order, an earlier request would sit in front of the loads the step waits for.
+    __device__ __forceinline__ void prefetch_row(int row_i)
+    {
+        if ((unsigned)row_i >= (unsigned)n) return;
+        const double *row = C + (size_t)row_i * n;
+#pragma unroll
+        for (int qd = 0; qd < (CH + 1) / 2; ++qd) {
+            int col = base + qd * 128 + lane * 2;
+            if (CH == 1 && lane >= 32) col = base;  // (64 columns = 32 lanes' worth)
+            col = (col < n - 2) ? col : n - 2;
+            if (col < 0) col = 0;
+            dma_request16(row + col, dummy_lds);
+        }
+        for (int e0 = 0; e0 < nfl; e0 += 64) {
+            const int e = e0 + lane;
+            int col = (e < nfl) ? fl[e] : base;
+            col = (col < n - 2) ? col : n - 2;
+            if (col < 0) col = 0;
+            dma_request16(row + col, dummy_lds);
+        }
+    }
+    // a column from another member's range now sits at one of this member's positions
+    __device__ __forceinline__ void foreign_push(int col)
+    {
+        if ((unsigned)(col - base) >= (unsigned)P && nfl < kFL) {
+            if (lane == 0) fl[nfl] = col;
+            ++nfl;
+        }
     }
 
     // ---------------------------------------------------------------- path start (lapjv.cpp:233-237)
@@ -180,6 +323,7 @@ struct Member {
         paths++;
         init_elems += n;
         lo = hi = ready = 0;
+        nfl = 0;
     }
 
     // ---------------------------------------------------------------- minima collection (lapjv.cpp:153-171, :243-256)
@@ -218,22 +362,26 @@ struct Member {
 
         // ---- round A: every member's (minimum, first position, column, matched row)
         ++seq;
-        publish(lo32(wtv), hi32(wtv), (unsigned)wtp, (unsigned)mj_own, (unsigned)(my_own + 1),
-                (err ? kFlagErr : 0u) | ((unsigned)mp_own << 4));
+        publish(lo32(wtv), hi32(wtv), (unsigned)((wtp != 0x7fffffff) ? wtp : 0xffff) | ((unsigned)(my_own + 1) << 16),
+                (unsigned)mj_own | ((unsigned)mp_own << 14) | ((err ? kFlagErr : 0u) << 28), false);
         if (!poll(NGm)) {
             err = 20;
             return kRcErr;
         }
-        if (const int rc = check_flags(5, 0)) return rc;
+        if (const int rc = check_flags(3, 28)) return rc;
         double mv = pos_inf();
         int mp = 0x7fffffff, mcol = 0, mrow = -1, mpred = 0;
-        if (lane < G) {
-            const unsigned *rec = rx + lane * kK;
+        {
+            const unsigned r0 = member_word(0), r1 = member_word(1), r2 = member_word(2), r3 = member_word(3);
+            const unsigned rec[4] = {r0, r1, r2, r3};
+            if (lane < G) {
             mv = mk_f64(rec[0], rec[1]);
-            mp = (int)rec[2];
-            mcol = (int)rec[3];
-            mrow = (int)rec[4] - 1;
-            mpred = (int)(rec[5] >> 4);
+            mp = (int)(rec[2] & 0xffffu);
+            if (mp == 0xffff) mp = 0x7fffffff;
+            mrow = (int)(rec[2] >> 16) - 1;
+            mcol = (int)(rec[3] & 0x3fffu);
+            mpred = (int)((rec[3] >> 14) & 0x3fffu);
+            }
         }
         double pv = mv, totv;
         int pp = mp, totp;
@@ -312,7 +460,7 @@ struct Member {
         // positions in a way that needs the whole ordered event list: not handled here)
         const unsigned long long anytie_local = __ballot(tie);
         ++seq;
-        publish((anytie_local ? 4u : 0u) | (err ? kFlagErr : 0u), 0, 0, 0, 0, 0);
+        publish((anytie_local ? 4u : 0u) | (err ? kFlagErr : 0u), 0, 0, 0, false);
         if (!poll(NGm)) {
             err = 20;
             return kRcErr;
@@ -320,7 +468,12 @@ struct Member {
         if (const int rc = check_flags(0, 0)) return rc;
         {
             unsigned f = 0;
-            if (lane < G) f = rx[lane * kK] & 4u;
+            if constexpr (kWideRec) {
+                const unsigned w = member_word(0);
+                if (lane < G) f = w & 4u;
+            } else {
+                if (lane < NGm && (lane & (kK - 1)) == 0) f = gv[0] & 4u;
+            }
             if (__ballot(f != 0)) {
                 bail_reason = 1;
                 return kRcBail;
@@ -348,6 +501,13 @@ struct Member {
                 vr[r] = ld_f64(v + pc[r]);
             }
         }
+        // (only the first strict event of a member can receive a column from an earlier member: pcol)
+        {
+            bool got_foreign = false;
+#pragma unroll
+            for (int r = 0; r < CH; ++r) got_foreign |= ((sb >> r) & 1u) && prevpos[r] < base;
+            if (__ballot(got_foreign)) foreign_push(pcol);
+        }
         if (totp != lo && (unsigned)(lo - b0) < (unsigned)CH) {
 #pragma unroll
             for (int r = 0; r < CH; ++r) {
@@ -372,14 +532,24 @@ struct Member {
         }
         const double *row = C + (size_t)head_i * n;
         double c[CH];
+        CSTAMP(ts0);
 #pragma unroll
-        for (int r = 0; r < CH; ++r) c[r] = row[umin_u32((unsigned)jr[r], (unsigned)(n - 1))];
+        for (int r = 0; r < CH; ++r) {
+            // SCAN / READY positions are not relaxed: point them at the head's own entry (one line every
+            // lane reads anyway) instead of a column whose line nobody prefetched
+            const int k = b0 + r;
+            const int jc = ((k >= hi) & (k < n)) ? jr[r] : head_j;
+            c[r] = row[umin_u32((unsigned)jc, (unsigned)(n - 1))];
+        }
         const double c_head = row[head_j];
         const double v_head = ld_f64(v + head_j);
         scan_steps++;
         scan_elems += (long long)(n - hi);
 #pragma unroll
         for (int r = 0; r < CH; ++r) pin(c[r]);
+        CSTAMP_WAIT();
+        CSTAMP(ts1);
+        CSTAMP_ADD(0, ts1, ts0);
         const double h = (c_head - v_head) - level;  // (cost - v) - level : lapjv.cpp:189
         unsigned evm = 0;
 #pragma unroll
@@ -393,12 +563,14 @@ struct Member {
             pr[r] = imp ? head_i : pr[r];
             evm |= ev ? (1u << r) : 0u;
         }
+        if (lo + 1 < hi) prefetch_row(uni(q[(lo + 1) & (kQ - 1)].y));
         for (int round = 0;; ++round) {
             // ---- this member's pending tie events, in position order
+            CSTAMP(tr0);
             int cnt = 0;
 #pragma unroll
             for (int r = 0; r < CH; ++r) cnt += __popcll(__ballot((evm >> r) & 1u));
-            unsigned e0a = 0, e0b = 0, e1a = 0, e1b = 0, e2a = 0, e2b = 0;
+            unsigned e0a = 0, e0b = 0, e1a = 0, e1b = 0;
             if (cnt) {
                 unsigned long long any = __ballot(evm != 0);
                 int emitted = 0;
@@ -424,12 +596,9 @@ struct Member {
                         if (emitted == 0) {
                             e0a = wa;
                             e0b = yv;
-                        } else if (emitted == 1) {
+                        } else {
                             e1a = wa;
                             e1b = yv;
-                        } else {
-                            e2a = wa;
-                            e2b = yv;
                         }
                         ++emitted;
                     }
@@ -438,52 +607,128 @@ struct Member {
             e0b |= (unsigned)(cnt > 255 ? 255 : cnt) << 20;
             e0b |= (err ? kFlagErr : 0u) << 28;
             ++seq;
+            CSTAMP(tr1);
+            CSTAMP_ADD(1, tr1, tr0);
             // ---- the columns at order[hi .. hi+3] (what this round's events displace), with their
-            // matched rows and distances as they stand after this step's update
-            {
-                unsigned long long *win = mail + (size_t)(seq & 1u) * NGtot + NGm;
+            // predecessors, matched rows, distances and duals as they stand after this step's update:
+            // the one or two lanes that own those positions stage ALL their positions (one exec-masked
+            // block, no per-position branches); the storing lanes pick the four slots out of that
+            if ((unsigned)(hi + kWin - 1 - base) < (unsigned)(P + kWin - 1)) {
+                const int L0 = (hi >= base) ? (hi - base) / CH : 0;  // first lane of this member inside the window
+                const int row = lane - L0;
+                if ((unsigned)row < 4u) {
 #pragma unroll
-                for (int r = 0; r < CH; ++r) {
-                    const int k = b0 + r;
-                    const unsigned t = (unsigned)(k - hi);
-                    if (t < (unsigned)kWin && k < n) {
-                        st_gran(win + 4 * t + 0, seq, (unsigned)jr[r] | ((unsigned)pr[r] << 16));
-                        st_gran(win + 4 * t + 1, seq, (unsigned)(yr[r] + 1));
-                        st_gran(win + 4 * t + 2, seq, lo32(dk[r]));
-                        st_gran(win + 4 * t + 3, seq, hi32(dk[r]));
+                    for (int r = 0; r < CH; ++r) {
+                        unsigned *d = wb + (row * CH + r) * kSlot;
+                        d[0] = (unsigned)jr[r] | ((unsigned)pr[r] << 16);
+                        d[1] = (unsigned)(yr[r] + 1);
+                        d[2] = lo32(dk[r]);
+                        d[3] = hi32(dk[r]);
+                        d[4] = lo32(vr[r]);
+                        d[5] = hi32(vr[r]);
                     }
                 }
-                // slots beyond the last position: nobody owns them, the last member fills them in
-                if (g == G - 1 && hi + kWin > n && lane < kWinGran) {
-                    const int t = lane >> 2;
-                    if (hi + t >= n) st_gran(win + lane, seq, 0u);
-                }
             }
-            publish(e0a, e0b, e1a, e1b, e2a, e2b);
+            publish(e0a, e0b, e1a, e1b, true);
+            CSTAMP(tr2);
+            CSTAMP_ADD(2, tr2, tr1);
             if (!poll(NGm + kWinGran)) {
                 err = 20;
                 return kRcErr;
             }
+            CSTAMP(tr3);
+            CSTAMP_ADD(3, tr3, tr2);
+            CSTAMP_INC(8);
             if (const int rc = check_flags(1, 28)) return rc;
+            // event counts, on the lanes that hold word 1 of a member record
+            // (more than 16 members: on lane m for member m, fetched by a cross-lane read)
             int cm = 0;
-            if (lane < G) cm = (int)((rx[lane * kK + 1] >> 20) & 0xffu);
+            if constexpr (kWideRec) {
+                const unsigned w = member_word(1);
+                if (lane < G) cm = (int)((w >> 20) & 0xffu);
+            } else {
+                if (lane < NGm && (lane & (kK - 1)) == 1) cm = (int)((gv[0] >> 20) & 0xffu);
+            }
+            const unsigned long long evl = __ballot(cm > 0);
+            if (evl == 0ull) {
+                CSTAMP(tr4);
+                CSTAMP_ADD(4, tr4, tr3);
+                break;
+            }
+            const int first_l = __builtin_ctzll(evl);
+            if ((evl & (evl - 1)) == 0ull && __builtin_amdgcn_readlane(cm, first_l) == 1) {
+                // ---- exactly one tie event in the whole step (60% of the steps that have any)
+                const int gb = kWideRec ? first_l * kK : first_l - 1;  // first granule of that member's record
+                const unsigned wa = rxu(gb), wbv = rxu(gb + 1);
+                const int ep = (int)(wa & 0xffffu), ej = (int)(wa >> 16), ey = (int)(wbv & 0xfffffu) - 1;
+                const unsigned w0 = rxu(NGm);
+                const int a = (int)(w0 & 0xffffu), qa = (int)(w0 >> 16), ya = (int)rxu(NGm + 1) - 1;
+                const int t = ep - hi;
+                if ((unsigned)ep >= (unsigned)n || (unsigned)ej >= (unsigned)n || ey >= n || t < 0 ||
+                    (unsigned)a >= (unsigned)n || ya >= n || (unsigned)qa >= (unsigned)n) {
+                    err = 8;
+                    return kRcErr;
+                }
+                if (ey < 0) {
+                    target = ej;
+                    if (g == 0 && lane == 0) st_i32(pred + ej, head_i);
+                    return kRcTarget;
+                }
+                if (t != 0 && (unsigned)(ep - base) < (unsigned)P) {
+                    foreign_push(a);
+                    const double da = mk_f64(rxu(NGm + 2), rxu(NGm + 3)), va = mk_f64(rxu(NGm + 4), rxu(NGm + 5));
+#pragma unroll
+                    for (int r = 0; r < CH; ++r) {
+                        if (b0 + r == ep) {
+                            jr[r] = a;
+                            yr[r] = ya;
+                            pr[r] = qa;
+                            dk[r] = da;
+                            vr[r] = va;
+                        }
+                    }
+                }
+                if ((unsigned)(hi - base) < (unsigned)P) {
+#pragma unroll
+                    for (int r = 0; r < CH; ++r) {
+                        if (b0 + r == hi) {
+                            jr[r] = ej;
+                            yr[r] = ey;
+                            pr[r] = head_i;
+                            dk[r] = level;
+                        }
+                    }
+                }
+                if (lane == 0) {
+                    q[hi & (kQ - 1)] = make_int2(ej, ey);
+                    if (g == 0) st_i32(pred + ej, head_i);
+                }
+                ++hi;
+                if (hi - lo >= kQ) {
+                    bail_reason = 2;
+                    return kRcBail;
+                }
+                CSTAMP(tr6);
+                CSTAMP_ADD(6, tr6, tr3);
+                break;
+            }
             const int total = wave_sum_i32(cm);
-            if (total == 0) break;
             // ---- the first events of the round in global position order = member order
             int take = 0;
             int ep0 = 0, ep1 = 0, ep2 = 0, ep3 = 0, ej0 = 0, ej1 = 0, ej2 = 0, ej3 = 0, ey0 = 0, ey1 = 0, ey2 = 0, ey3 = 0;
             {
-                unsigned long long mm = __ballot(cm > 0);
+                unsigned long long mm = evl;
                 bool blocked = false;
                 while (mm && take < kWin && !blocked) {
-                    const int m = __builtin_ctzll(mm);
+                    const int ml = __builtin_ctzll(mm);  // lane holding word 1 of that member's record
                     mm &= mm - 1;
-                    const int c_m = __builtin_amdgcn_readlane(cm, m);
+                    const int m = kWideRec ? ml : (ml >> 2);
+                    const int c_m = __builtin_amdgcn_readlane(cm, ml);
                     const int pub = (c_m < kEmax) ? c_m : kEmax;
                     for (int e = 0; e < pub && take < kWin; ++e) {
                         const unsigned wa = rxu(m * kK + 2 * e);
-                        const unsigned wb = rxu(m * kK + 2 * e + 1);
-                        const int pp_ = (int)(wa & 0xffffu), jj_ = (int)(wa >> 16), yy_ = (int)(wb & 0xfffffu) - 1;
+                        const unsigned wbv = rxu(m * kK + 2 * e + 1);
+                        const int pp_ = (int)(wa & 0xffffu), jj_ = (int)(wa >> 16), yy_ = (int)(wbv & 0xfffffu) - 1;
                         if (take == 0) {
                             ep0 = pp_, ej0 = jj_, ey0 = yy_;
                         } else if (take == 1) {
@@ -523,14 +768,15 @@ struct Member {
             }
             // ---- replay the swaps cols[k] = cols[hi]; cols[hi++] = j (lapjv.cpp:203-204) on the window
             int wa_[kWin], wy_[kWin], wq_[kWin];
-            double wd_[kWin];
+            double wd_[kWin], wv_[kWin];
 #pragma unroll
             for (int t = 0; t < kWin; ++t) {
-                const unsigned w0 = rxu(NGm + 4 * t);
+                const unsigned w0 = rxu(NGm + kSlot * t);
                 wa_[t] = (int)(w0 & 0xffffu);
                 wq_[t] = (int)(w0 >> 16);
-                wy_[t] = (int)rxu(NGm + 4 * t + 1) - 1;
-                wd_[t] = mk_f64(rxu(NGm + 4 * t + 2), rxu(NGm + 4 * t + 3));
+                wy_[t] = (int)rxu(NGm + kSlot * t + 1) - 1;
+                wd_[t] = mk_f64(rxu(NGm + kSlot * t + 2), rxu(NGm + kSlot * t + 3));
+                wv_[t] = mk_f64(rxu(NGm + kSlot * t + 4), rxu(NGm + kSlot * t + 5));
             }
             const int eps[kWin] = {ep0, ep1, ep2, ep3};
             const int ejs[kWin] = {ej0, ej1, ej2, ej3};
@@ -539,7 +785,7 @@ struct Member {
             for (int s = 0; s < kWin; ++s) {
                 if (s < take) {
                     const int a = wa_[s], ya = wy_[s], qa = wq_[s];
-                    const double da = wd_[s];
+                    const double da = wd_[s], va = wv_[s];
                     const int t = eps[s] - hi;  // >= s: the events are in position order
                     if ((unsigned)eps[s] >= (unsigned)n || (unsigned)ejs[s] >= (unsigned)n || eys[s] >= n ||
                         (unsigned)a >= (unsigned)n || ya >= n || (unsigned)qa >= (unsigned)n || t < s) {
@@ -554,12 +800,13 @@ struct Member {
                             wq_[u] = qa;
                             wy_[u] = ya;
                             wd_[u] = da;
+                            wv_[u] = va;
                             moved_inside = true;
                         }
                     }
                     if (!moved_inside && t != s && (unsigned)(eps[s] - base) < (unsigned)P) {
                         // the event position adopts the column displaced from order[hi + s]
-                        const double va = ld_f64(v + a);
+                        foreign_push(a);
 #pragma unroll
                         for (int r = 0; r < CH; ++r) {
                             if (b0 + r == eps[s]) {
@@ -595,6 +842,8 @@ struct Member {
                 bail_reason = 2;
                 return kRcBail;  // uniform: every member computes the same hi, lo
             }
+            CSTAMP(tr5);
+            CSTAMP_ADD(5, tr5, tr3);
             if (total == take) break;
             // more events than one round could carry: drop the ones just applied and go again
 #pragma unroll
@@ -631,7 +880,7 @@ struct Member {
         }
         drain();  // v[] and every pred[] store of this path have left before the ack record does
         ++seq;
-        publish(err ? kFlagErr : 0u, 0, 0, 0, 0, 0);
+        publish(err ? kFlagErr : 0u, 0, 0, 0, false);
         if (!poll(NGm)) {
             err = 20;
             return kRcErr;
@@ -661,7 +910,7 @@ struct Member {
             drain();
         }
         ++seq;
-        publish(err ? kFlagErr : 0u, 0, 0, 0, 0, 0);
+        publish(err ? kFlagErr : 0u, 0, 0, 0, false);
         if (!poll(NGm)) {
             err = 20;
             return kRcErr;
@@ -675,8 +924,10 @@ template <int CH, int NL>
 __global__ void __launch_bounds__(64) coop_ssp_kernel(CoopParams p)
 {
     __shared__ int2 q_s[kQ];
-    __shared__ unsigned rx_s[NL * 64];
     __shared__ int2 lj_s[64 * CH];
+    __shared__ unsigned wb_s[4 * CH * kSlot];
+    __shared__ int fl_s[kFL];
+    __shared__ __attribute__((aligned(16))) unsigned char dummy_s[1024];
     // members of instance b sit at block indices with the same value modulo 8: workgroups are dealt
     // to the 8 XCDs round robin, so they share an XCD (speed only -- nothing depends on it)
     const int G = p.G;
@@ -706,19 +957,27 @@ __global__ void __launch_bounds__(64) coop_ssp_kernel(CoopParams p)
     m.NGtot = G * kK + kWinGran;
     m.mail = p.mail + (size_t)b * 2 * m.NGtot;
     m.q = q_s;
-    m.rx = rx_s;
     m.lj = lj_s;
+    m.wb = wb_s;
+    m.fl = fl_s;
+    m.nfl = 0;
+    m.dummy_lds = lds_address(dummy_s);
     m.seq = 0;
     m.scan_elems = m.init_elems = 0;
     m.paths = m.finds = m.scan_steps = 0;
     m.err = 0;
     m.bail_reason = 0;
+#ifdef LAPWARM_COOP_STAMPS
+    for (int qd = 0; qd < 10; ++qd) m.stamps[qd] = 0;
+#endif
     m.level = 0.0;
     m.lo = m.hi = m.ready = m.head_i = m.head_j = 0;
     const int *fr = p.fr + o;
 
+    m.allow_xcd_stores = p.xcd_stores != 0;
     int done = 0;
-    for (int f = 0; f < nf; ++f) {
+    m.setup_round();
+    for (int f = 0; f < nf && !m.err; ++f) {
         const long long s_scan = m.scan_elems, s_init = m.init_elems;
         const int s_paths = m.paths, s_finds = m.finds, s_steps = m.scan_steps;
         const int start = uni(fr[f]);
@@ -726,11 +985,24 @@ __global__ void __launch_bounds__(64) coop_ssp_kernel(CoopParams p)
             m.err = 2;
             break;
         }
-        m.path_init(start);
+        {
+            CSTAMP(tpa);
+            m.path_init(start);
+            CSTAMP_WAIT();
+            CSTAMP(tpb);
+#ifdef LAPWARM_COOP_STAMPS
+            m.stamps[9] += (long long)(tpb - tpa);
+#endif
+        }
         int target = -1, rc = kRcGo;
         for (int guard = 0;; ++guard) {
             if (m.lo == m.hi) {
+                CSTAMP(tca);
                 rc = m.collect(target);
+                CSTAMP(tcb);
+#ifdef LAPWARM_COOP_STAMPS
+                m.stamps[7] += (long long)(tcb - tca);
+#endif
                 if (rc) break;
             }
             rc = m.relax(target);
@@ -751,7 +1023,15 @@ __global__ void __launch_bounds__(64) coop_ssp_kernel(CoopParams p)
             break;
         }
         if (rc == kRcErr) break;
-        if (m.path_end(target, start)) break;
+        {
+            CSTAMP(tpa);
+            const int prc = m.path_end(target, start);
+            CSTAMP(tpb);
+#ifdef LAPWARM_COOP_STAMPS
+            m.stamps[9] += (long long)(tpb - tpa);
+#endif
+            if (prc) break;
+        }
         done = f + 1;
     }
     if (g == 0 && m.lane == 0) {
@@ -764,7 +1044,10 @@ __global__ void __launch_bounds__(64) coop_ssp_kernel(CoopParams p)
         cs[2] = m.scan_steps;
         cs[3] = m.scan_elems;
         cs[4] = m.init_elems;
-        cs[5] = (long long)m.seq;
+        cs[5] = (long long)m.seq | (m.same_xcd ? (1ll << 40) : 0);
+#ifdef LAPWARM_COOP_STAMPS
+        for (int qd = 0; qd < 10; ++qd) cs[6 + qd] = m.stamps[qd];
+#endif
     } else if (m.err && m.lane == 0) {
         // a member other than the leader saw the error first: make sure it is not lost
         atomicMax(&hand[4], m.err);
@@ -789,7 +1072,7 @@ int coop_ch(int n)
         return e ? atoi(e) : 0;
     }();
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8 || forced == 16) {
-        if ((n + 64 * forced - 1) / (64 * forced) <= 18) return forced;
+        if ((n + 64 * forced - 1) / (64 * forced) <= 32) return forced;
     }
     // Measured (tools/micro/hop_bench.hip, profiles/r03_hop_bench.txt): an exchange among 8 members costs
     // 1.0-1.3 us, among 16 1.4-2.2 us (32 instances in flight), among 32 1.9-2.6 us -- the fewer members the
@@ -797,8 +1080,7 @@ int coop_ch(int n)
     if (n <= 512) return 1;
     if (n <= 1024) return 2;
     if (n <= 2048) return 4;
-    if (n <= 4096) return 8;
-    return 16;  // 8192 -> 8 members, 16384 -> 16
+    return 8;  // measured: n = 8192 1.36 s with 8 (16 members), 1.64 s with 16, 1.50 s with 4; n = 16384 4.03 s with 8, 4.78 s with 16
 }
 
 int coop_members(int n)
@@ -813,7 +1095,9 @@ bool coop_enabled(int n)
 {
     static const int min_n = [] {
         const char *e = getenv("LAPWARM_COOP_MIN_N");
-        return e ? atoi(e) : 4096;
+        // default: sizes whose solver state no longer fits one CU's LDS (solver_lds_level 0); below that the
+        // single-workgroup kernel is faster (n = 4096: 274 ms against 442 ms per 32 instances)
+        return e ? atoi(e) : 4428;
     }();
     static const int on = [] {
         const char *e = getenv("LAPWARM_COOP");
@@ -821,7 +1105,7 @@ bool coop_enabled(int n)
     }();
     const int ch = coop_ch(n);
     return on && n >= min_n && n <= 16384 && (ch == 1 || ch == 2 || ch == 4 || ch == 8 || ch == 16) &&
-           coop_members(n) <= 18;
+           coop_members(n) <= 32;
 }
 
 hipError_t launch_coop(const CoopParams &p_in, hipStream_t stream)
@@ -830,6 +1114,11 @@ hipError_t launch_coop(const CoopParams &p_in, hipStream_t stream)
     const int ch = coop_ch(p.n);
     p.G = coop_members(p.n);
     const int ng = p.G * kK + kWinGran;
+    static const int xcd_stores = [] {
+        const char *e = getenv("LAPWARM_COOP_XCD_STORES");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    p.xcd_stores = xcd_stores;
     const int nl = (ng + 63) / 64;
     // every member of an instance must be resident while the instance runs: at most 1024 single-wave
     // workgroups per launch (a quarter of what the chip holds), instances in groups of 8
@@ -850,6 +1139,9 @@ hipError_t launch_coop(const CoopParams &p_in, hipStream_t stream)
         LAPWARM_COOP_CASE(4)
         LAPWARM_COOP_CASE(8)
         LAPWARM_COOP_CASE(16)
+        // 17 .. 32 members (three granule loads per lane): n = 8192 with 4, n = 16384 with 8 positions per lane
+        if (nl == 3 && ch == 4) e = launch_cfg<4, 3>(p, grid, stream);
+        if (nl == 3 && ch == 8) e = launch_cfg<8, 3>(p, grid, stream);
 #undef LAPWARM_COOP_CASE
         if (e != hipSuccess) return e;
     }

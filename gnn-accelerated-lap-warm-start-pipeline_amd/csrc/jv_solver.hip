@@ -1874,7 +1874,9 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
                                        ((long long)p.hand[(size_t)b * kHandInts + 3] << 32))
                                     : -1;
             for (int q = 16; q < kStatsPerInstance; ++q) st[q] = 0;
-            if (p.phase == 2 && p.cstats) st[16] = p.cstats[(size_t)b * kCoopStats + 5];  // exchange rounds
+            if (p.phase == 2 && p.cstats) {
+                for (int q = 0; q < 11; ++q) st[16 + q] = p.cstats[(size_t)b * kCoopStats + 5 + q];  // exchange rounds; stamps
+            }
 #ifdef LAPWARM_STAMPS
             for (int q = 0; q < 16; ++q) st[16 + q] = s.stamps[q];
 #endif

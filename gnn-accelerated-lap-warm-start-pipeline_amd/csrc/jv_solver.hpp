@@ -64,13 +64,14 @@ constexpr int kRingInts = 2 + kRingSlots;
 // and phase 2 reports (branch, tight edges, free rows after greedy, micro-ARR firings, transfer
 // rows, ARR iterations, column-reduction elements lo/hi, phase-1 error)
 constexpr int kHandInts = 16;
-constexpr int kCoopStats = 8;
+constexpr int kCoopStats = 16;
 
 struct CoopParams {
     const double *C;
     int n, batch;
     int G;             // members (single-wave workgroups) per instance, filled in by launch_coop
     int first, count;  // instances [first, first + count) of this launch
+    int xcd_stores;    // allow workgroup-scope mailbox stores when all members of an instance share an XCD
     double *v;         // [batch][n] column duals (the solver's global state arrays)
     int *x, *y, *pred;
     const int *fr;     // [batch][n] free rows, hand[0] of them

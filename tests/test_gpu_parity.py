@@ -538,12 +538,21 @@ def test_two_stream_pipeline_and_graph_capture_match_eager(torch_cuda):
     static_C = C1.clone()
     with torch.cuda.graph(g):
         out = pipe.solve_batch(static_C)
-    for src, ref in ((C1, ref1), (C2, ref2)):
+    ws = pipe._workspace(B, n)[0]
+    for rep, (src, ref) in enumerate(((C1, ref1), (C2, ref2), (C1, ref1))):
         static_C.copy_(src)
+        # Poison the whole solver workspace before the replay: every word the captured kernels read
+        # (seeds, per-instance flags, helper ring, tight bitmaps, global solver state) must be
+        # written inside the captured chain itself.  A stale word -- the flake of round 2 -- would
+        # now be 0xFF.. instead of "whatever the previous replay left", and names itself below.
+        ws.fill_(0xFF)
         g.replay()
         torch.cuda.synchronize()
+        st = out["stats"].cpu().numpy()
+        assert out["ret"].tolist() == ref["ret"].tolist(), (rep, out["ret"].tolist(), st[:, 12].tolist(), st[:, 0].tolist())
+        assert not st[:, 12].any(), (rep, st[:, 12].tolist())
         for key in ("x", "y", "ret", "u", "v"):
-            assert torch.equal(out[key], ref[key]), key
+            assert torch.equal(out[key], ref[key]), (rep, key)
 
 
 @pytest.mark.parametrize("n,hint", [(1024, 1024), (1024, 512), (1024, 256), (2048, 1024), (2048, 512)])
