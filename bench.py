@@ -322,8 +322,10 @@ def run_rank(args):
         alg_bytes = 8.0 * E
         achieved = alg_bytes / (solver_avg_ms * 1e-3) / 1e9
         branches = {int(k): int(c) for k, c in zip(*np.unique(stats[:, 0], return_counts=True))}
-        cus_busy = min(B, N_CUS)  # one workgroup = one instance = one CU
         from lap import _hip as _h
+        members = int(_h.load().lapwarm_coop_members(n))  # > 0: cooperative shortest-path kernel (n >= 4428)
+        # one workgroup = one instance = one CU, or `members` single-wave workgroups per instance
+        cus_busy = min(B * max(1, members), N_CUS)
         helpers = bool(_h.load().lapwarm_solver_uses_helpers(n))
         cus_kernel = min(2 * B, N_CUS) if helpers else cus_busy  # + one (mostly idle) helper CU per instance
         # (the grid pads the batch to a multiple of 8 so that helper and solver share an XCD; padding exits at once)
@@ -354,12 +356,16 @@ def run_rank(args):
                                   if overlap else "none (stages back to back on one stream)"),
                 "solver_threads_hint": args.threads_hint,
                 "solver_helper_workgroups": helpers,
+                "solver_coop_members_per_instance": members,
                 "branches": branches,
                 "ret_nonzero": int((ret != 0).sum()),
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "jv_instance_kernel (per-instance seeded JV: greedy, micro-ARR, SSP / cold-JV fallback)",
+                "kernel": ("jv_instance_kernel (greedy, micro-ARR) + coop_ssp_kernel (shortest paths, %d single-wave "
+                           "members per instance) + jv_instance_kernel (outputs): the three launches of one solve" % members
+                           if members else
+                           "jv_instance_kernel (per-instance seeded JV: greedy, micro-ARR, SSP / cold-JV fallback)"),
                 "achieved": round(achieved, 3),
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",

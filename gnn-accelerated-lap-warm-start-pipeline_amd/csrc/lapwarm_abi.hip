@@ -192,7 +192,9 @@ int lapwarm_refine_aggregate_batched(const float *topk16, const float *u_pre, co
     return lapwarm_refine_aggregate_wsum(topk16, u_pre, w1, b1, out, nullptr, rows, H, stream_);
 }
 
-int lapwarm_solver_uses_helpers(int n) { return solver_uses_helpers(n) ? 1 : 0; }
+int lapwarm_solver_uses_helpers(int n) { return (solver_uses_helpers(n) && !coop_enabled(n)) ? 1 : 0; }
+
+int lapwarm_coop_members(int n) { return (n > 0 && coop_enabled(n)) ? coop_members(n) : 0; }
 
 const char *lapwarm_build_info(void) { return "liblapwarm_hip gfx950 (hand-written HIP, fp64)"; }
 

@@ -52,6 +52,7 @@ SIGNATURES = {
     "lapwarm_profile_enable": (None, [ct.c_int]),
     "lapwarm_profile_last_solver_ms": (ct.c_double, []),
     "lapwarm_solver_uses_helpers": (ct.c_int, [ct.c_int]),
+    "lapwarm_coop_members": (ct.c_int, [ct.c_int]),
     "lapwarm_last_error": (ct.c_char_p, []),
     "lapwarm_device_count": (ct.c_int, []),
     "lapwarm_build_info": (ct.c_char_p, []),

@@ -148,6 +148,12 @@ double lapwarm_profile_last_solver_ms(void);
  * the solver kernel then occupies about 2 * batch CUs.  n = 1024 .. 8192. */
 int lapwarm_solver_uses_helpers(int n);
 
+/* Number of single-wave workgroups ("members", one compute unit each) that share ONE instance's
+ * shortest-augmenting-path phase for this n, or 0 when that phase runs inside the one-workgroup-per-
+ * instance kernel (n < 4428 by default; LAPWARM_COOP=0 / LAPWARM_COOP_MIN_N change it).  New, additive:
+ * the reference has no counterpart (its _ca_dense, LAP/_lapjv_cpp/lapjv.cpp:286-319, is serial). */
+int lapwarm_coop_members(int n);
+
 /* Misc */
 const char *lapwarm_last_error(void);
 int lapwarm_device_count(void);

@@ -372,6 +372,54 @@ def test_large_n_pipeline_exact(torch_cuda, n):
     assert st[6] == so["scan_steps"] and st[4] == so["paths"] and st[7] == so["scan_elems"]
 
 
+def test_cooperative_kernel_forced_on_small_sizes_native_sweep():
+    """The cooperative shortest-path kernel (coop_ssp.hip: one instance over several single-wave
+    workgroups, normally n >= 4428) forced on for EVERY size (LAPWARM_COOP_MIN_N=1): the native sweep
+    to n = 512 -- 10 families x 7 seed kinds, cold solves included -- must stay bit-exact.  Tie-heavy
+    families make the kernel stop at a path boundary and hand the rest to jv_instance_kernel's
+    resume phase, so the sweep covers the hand-over in both directions; sizes 1 .. 63 run with a
+    single, partly empty member."""
+    exe = ROOT / "tests" / "native" / "_build" / "parity_driver"
+    env = dict(os.environ, LAPWARM_COOP_MIN_N="1")
+    proc = subprocess.run([str(exe), "512", "1"], capture_output=True, text=True, timeout=900, env=env)
+    assert proc.returncode == 0, proc.stdout[-3000:]
+    assert "bad=0" in proc.stdout.splitlines()[-1]
+
+
+@pytest.mark.parametrize("fams", [("uniform", "sparse"), ("tie", "clustered")])
+def test_cooperative_kernel_at_its_threshold_size(torch_cuda, fams):
+    """n = 4608 (the first sizes whose solver state leaves LDS run the cooperative kernel, 9 members
+    of 512 positions): continuous costs stay in it for every path; sparse / tie / clustered costs
+    produce tie collections, where it stops and jv_instance_kernel resumes.  Assignments bit-exact
+    and the path / collection / relax-step / element counters equal to the oracle's either way --
+    the counters of the two kernels add up to the serial algorithm's."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    from gnn.features import min_trick_device
+    from oracle import jv
+    from solvers.generators import mixed_batch
+    B, n = 4, 4608
+    Cs, names = mixed_batch(B, n, families=fams, seed=99)
+    pipe = WarmStartPipeline(OneGNN(21, hidden=64, layers=2).eval(), "cuda:0")
+    C = torch.from_numpy(Cs).cuda()
+    u = C.min(dim=2).values.contiguous()
+    v = min_trick_device(C, u)
+    x, y, ret, stats = pipe.seeded_batch(C, u, v)
+    torch.cuda.synchronize()
+    st = stats.cpu().numpy()
+    assert (st[:, 15] >= 0).all(), "the cooperative kernel did not run at n = 4608"
+    coop_paths = st[:, 15] & 0xffffffff
+    un, vn = u.cpu().numpy(), v.cpu().numpy()
+    for b in range(B):
+        r, xo, yo, so = jv.seeded_raw(Cs[b], un[b], vn[b])
+        assert r == int(ret[b]) == 0, (names[b], r, int(ret[b]), st[b, 12])
+        assert np.array_equal(xo, x[b].cpu().numpy()) and np.array_equal(yo, y[b].cpu().numpy()), names[b]
+        for q, k in ((4, "paths"), (5, "finds"), (6, "scan_steps"), (7, "scan_elems"), (8, "init_elems")):
+            assert st[b, q] == so[k], (names[b], k, st[b, q], so[k])
+        if names[b] == "uniform" and so["branch"] == 1:
+            assert coop_paths[b] == so["paths"], (names[b], coop_paths[b], so["paths"])  # never left the kernel
+
+
 def test_k5_dense_stages_n16384(torch_cuda):
     """BASELINE config K5 (n=16384, top-16 refinement path): the dense stages on one instance.
     Row features (128-KiB LDS row) against the NumPy oracle on sampled rows, u against the
