@@ -593,7 +593,8 @@ def test_two_stream_pipeline_and_graph_capture_match_eager(torch_cuda):
         # (seeds, per-instance flags, helper ring, tight bitmaps, global solver state) must be
         # written inside the captured chain itself.  A stale word -- the flake of round 2 -- would
         # now be 0xFF.. instead of "whatever the previous replay left", and names itself below.
-        ws.fill_(0xFF)
+        with torch.inference_mode():  # (the workspace was allocated inside solve_batch's inference mode)
+            ws.fill_(0xFF)
         g.replay()
         torch.cuda.synchronize()
         st = out["stats"].cpu().numpy()
