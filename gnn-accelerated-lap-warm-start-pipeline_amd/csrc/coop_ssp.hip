@@ -181,8 +181,9 @@ struct Member {
             err = 20;
             return false;
         }
+        const unsigned w0 = member_word(0);  // (cross-lane read: every lane takes part)
         unsigned other = xcc | 0x100u;
-        if (lane < G) other = member_word(0);
+        if (lane < G) other = w0;
         same_xcd = (__ballot(other != (xcc | 0x100u)) == 0ull) && allow_xcd_stores;
         return true;
     }
