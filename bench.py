@@ -46,14 +46,28 @@ def serial_elems(stats_row, n):
     return int(stats_row[8] + stats_row[7] + stats_row[9] + n * stats_row[10] + n * stats_row[11])
 
 
+def solver_source_sha():
+    """Identity of the solver build a PMC record belongs to: sha256 of the kernel sources."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("jv_solver.hip", "coop_ssp.hip", "device_utils.hpp"):
+        h.update((PKG / "csrc" / f).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def recorded_traffic(kernel_prefix="jv_instance_kernel"):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
-    cannot run inside the timed process; see profiles/*_pmc_traffic.txt).  None if absent."""
+    cannot run inside the timed process; see profiles/*_pmc_traffic.txt).  Only a record taken from
+    THIS build of the solver counts (tools/summarize_pmc.py stores the source hash): a record of an
+    older kernel is refused rather than reported beside a newer kernel's time.  None if absent."""
     best = None
+    sha = solver_source_sha()
     for f in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json")):
         try:
             meta = json.loads(f.read_text())
         except Exception:
+            continue
+        if meta.get("solver_source_sha") != sha:
             continue
         for k, d in meta.get("kernels", {}).items():
             if k.startswith(kernel_prefix):
@@ -414,6 +428,30 @@ def run_rank(args):
                           % (len(idx), B, ",".join(names[b] for b in idx), cpu_dt),
             }
             line["parity_spot_check"] = {"instances": len(idx), "bit_exact": exact}
+            # the port against the reference's own C++ (oracle/_ref: built where /root/reference exists,
+            # travels as a prebuilt file): solver leg only, same (u, v), a few instances
+            try:
+                from oracle import ref as _ref
+                if _ref.LIB_PATH.exists():
+                    tp = tr = 0.0
+                    same = 0
+                    sub = idx[:4]
+                    for b in sub:
+                        t0 = time.perf_counter()
+                        rp, xp, _, _ = jv.seeded_raw(C_host[b], u[b], v[b])
+                        t1 = time.perf_counter()
+                        rr, xr, _ = _ref.seeded_raw(C_host[b], u[b], v[b])
+                        t2 = time.perf_counter()
+                        tp += t1 - t0
+                        tr += t2 - t1
+                        same += int(rp == rr and np.array_equal(xp, xr))
+                    line["cpu_baseline"]["port_over_reference"] = round(tp / max(tr, 1e-9), 3)
+                    line["cpu_baseline"]["port_over_reference_note"] = (
+                        "solver leg (lapjv_seeded) only: oracle/jv_oracle.c (with its element counters) against the "
+                        "reference's lapjv.cpp + lapjv_seeded.cpp compiled unmodified (oracle/_ref), %d instances, "
+                        "%d identical assignments" % (len(sub), same))
+            except Exception as e:  # the checker must never break the benchmark line
+                line["cpu_baseline"]["port_over_reference_note"] = "not measured: %s" % e
             if args.config == "K3" and not args.no_node_baseline:
                 nv, cores, total, slowest, wall = cpu_baseline_node(B, n, fams, 1234 + rank, args.hidden, args.layers)
                 line["cpu_baseline_node"] = {

@@ -569,11 +569,11 @@ struct Member {
             // ---- this member's pending tie events, in position order
             CSTAMP(tr0);
             int cnt = 0;
-#pragma unroll
-            for (int r = 0; r < CH; ++r) cnt += __popcll(__ballot((evm >> r) & 1u));
             unsigned e0a = 0, e0b = 0, e1a = 0, e1b = 0;
-            if (cnt) {
-                unsigned long long any = __ballot(evm != 0);
+            unsigned long long any = __ballot(evm != 0);  // (94% of the member-rounds: none)
+            if (any) {
+#pragma unroll
+                for (int r = 0; r < CH; ++r) cnt += __popcll(__ballot((evm >> r) & 1u));
                 int emitted = 0;
                 while (any && emitted < kEmax) {
                     const int l = __builtin_ctzll(any);

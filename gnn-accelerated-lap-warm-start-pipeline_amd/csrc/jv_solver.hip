@@ -2033,9 +2033,21 @@ static hipError_t launch_phase(const SolverParams &p_in, int threads_hint, hipSt
         return (k >= 1 && k <= 4) ? k : 1;
     }();
     // (a helper can only help while its solver runs: with more workgroups than CUs the helpers would
-    // be dispatched after the solvers they serve and leave at once -- skip them)
+    // be dispatched after the solvers they serve and leave at once -- skip them.  Assumptions, stated:
+    // workgroups are dispatched in index order, so every solver of THIS launch is resident before its
+    // helper; a helper spins until its solver's done flag or 0.5 s (60 s above n = 4096) and holds a
+    // CU's LDS meanwhile, so with several launches resident -- bench.py --inflight -- helpers can delay
+    // the solvers of a later launch, never deadlock them: every solver exit sets the flag.)
+    static const int n_cus = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+        }
+        return cus;
+    }();
     p.helper = (p.phase == 0 && p.mode == kModeSeeded && p.pf_ring && solver_uses_helpers(p.n) &&
-                p.batch * (1 + n_helpers) <= 256)
+                p.batch * (1 + n_helpers) <= n_cus)
                    ? n_helpers
                    : 0;
     int threads, ch;

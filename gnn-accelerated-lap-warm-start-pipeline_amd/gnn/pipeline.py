@@ -73,10 +73,16 @@ class WarmStartPipeline:
         key = (B, n)
         if key not in self._ws:
             if len(self._ws) >= 4:  # a handful of shapes at most: drop the oldest
+                # kernels of an earlier call may still be running on it (any stream), and a captured
+                # graph may hold its address: wait for the device before the block can be handed out again
+                torch.cuda.synchronize(self.device)
                 self._ws.pop(next(iter(self._ws)))
             nbytes = self.lib.lapwarm_seeded_workspace_bytes(B, n)
             self._ws[key] = (torch.empty((nbytes,), dtype=torch.uint8, device=self.device), nbytes)
-        return self._ws[key]
+        ws = self._ws[key]
+        # the caching allocator must not recycle the block while the stream that uses it now still runs
+        ws[0].record_stream(torch.cuda.current_stream(self.device))
+        return ws
 
     @torch.inference_mode()
     def predict_batch(self, C: torch.Tensor):
@@ -192,6 +198,9 @@ class WarmStartPipeline:
             done.record(s_solve)
         for t in (C, u, v):
             t.record_stream(s_solve)
+        # the results were allocated on the solver stream's pool and are consumed on the caller's
+        for t in (x, y, ret) + ((stats,) if stats is not None else ()):
+            t.record_stream(torch.cuda.current_stream(self.device))
         if C_next is not None:
             self.pipeline_submit(C_next)
         return {"x": x, "y": y, "ret": ret, "stats": stats, "u": u, "v": v, "done": done}

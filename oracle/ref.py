@@ -2,9 +2,10 @@
 
 liblap_ref.so is the reference's own C++ (LAP/_lapjv_cpp/lapjv.cpp and
 lapjv_seeded.cpp) compiled unmodified by oracle/Makefile where /root/reference
-exists.  It validates the restatement in jv_oracle.c and can serve as the CPU
-baseline (cpu_baseline.kind == "reference").  It is git-ignored and travels to
-the GPU box as a prebuilt file only.
+exists.  It validates the restatement in jv_oracle.c (tests/golden/make_golden.py,
+tests/test_oracle_golden.py) and bench.py times it beside the port on a few
+instances (cpu_baseline.port_over_reference).  It is git-ignored and travels to
+the GPU box as a prebuilt binary only -- no reference source does.
 """
 from __future__ import annotations
 

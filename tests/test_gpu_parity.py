@@ -523,9 +523,12 @@ def test_k3_config_full_size(torch_cuda):
             assert stats[b, q] == st[name], (b, fams[b], name, stats[b, q], st[name])
 
 
-def test_k4_config_slice(torch_cuda):
+@pytest.mark.parametrize("source", ["k4", "mixed"])
+def test_k4_config_slice(torch_cuda, source):
     """BASELINE configs[3] (K4: batch 256 over 8 GPUs, n=4096): one GPU's slice shape at a batch
-    the oracle finishes in under a minute (8 of the 32 instances, two per family).  n=4096 runs
+    the oracle finishes in under a minute -- 8 of the 32 instances, with K4's OWN input
+    (uniform RandomState(42 + i), scripts/gnn_large_scale_benchmark.py:243-251, exactly what
+    `bench.py --config K4` feeds rank 0) and with two instances per family.  n=4096 runs
     the solver with x / free-row list in global memory (LDS level 1) and 4 positions per thread.
     x/y bit-exact and counters equal to the oracle's, fed the GPU's own (u, v)."""
     torch = torch_cuda
@@ -533,8 +536,12 @@ def test_k4_config_slice(torch_cuda):
     from oracle import jv
     from solvers.generators import mixed_batch
     B, n = 8, 4096
-    Cs, fams = mixed_batch(B, n, seed=77)
-    assert sorted(set(fams)) == ["clustered", "metric", "sparse", "uniform"]
+    if source == "k4":
+        Cs = np.stack([np.random.RandomState(42 + i).uniform(0, 1, (n, n)) for i in range(B)])
+        fams = ["uniform"] * B
+    else:
+        Cs, fams = mixed_batch(B, n, seed=77)
+        assert sorted(set(fams)) == ["clustered", "metric", "sparse", "uniform"]
     torch.manual_seed(0)
     model = OneGNN(21, hidden=192, layers=4).eval()
     out = WarmStartPipeline(model, "cuda:0").solve_batch(torch.from_numpy(Cs).cuda())

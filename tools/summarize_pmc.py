@@ -24,7 +24,13 @@ for k, d in out.items():
     f = d.get("FETCH_SIZE", {}).get("mean_bytes_nonzero_launches", 0.0)
     w = d.get("WRITE_SIZE", {}).get("mean_bytes_nonzero_launches", 0.0)
     d["hbm_bytes_per_launch_corrected"] = 2.0 * f + w
-meta = {"workload": "bench.py K3 (batch 32, n 2048, mixed families)", "correction": "2*FETCH_SIZE + WRITE_SIZE (KiB counters)",
+import hashlib
+_h = hashlib.sha256()
+for _f in ("jv_solver.hip", "coop_ssp.hip", "device_utils.hpp"):
+    _h.update((ROOT / "gnn-accelerated-lap-warm-start-pipeline_amd" / "csrc" / _f).read_bytes())
+meta = {"workload": sys.argv[2] if len(sys.argv) > 2 else "bench.py K3 (batch 32, n 2048, mixed families)",
+        "correction": "2*FETCH_SIZE + WRITE_SIZE (KiB counters)",
+        "solver_source_sha": _h.hexdigest()[:16],  # bench.py only reports a record of the build it runs
         "kernels": out}
 (ROOT / "profiles" / f"{tag}_pmc_traffic.json").write_text(json.dumps(meta, indent=1))
 lines = [f"{'kernel':44s} {'FETCH raw MiB':>14s} {'WRITE MiB':>10s} {'HBM corrected MiB':>18s}"]
