@@ -242,8 +242,10 @@ def run_rank(args):
     elif args.config == "K4":  # batch=256 n=4096 over 8 GPUs -> 32 per GPU
         args.batch, args.n, args.families = 32, 4096, "uniform"
         args.cpu_sample = min(args.cpu_sample, 8)  # ~0.7 s per n=4096 instance on one core
-    elif args.config == "K5":  # n=16384, 2 GiB of fp64 costs per instance
-        args.batch, args.n, args.families = 1, 16384, "uniform"
+    elif args.config == "K5":  # n=16384, 2 GiB of fp64 costs per instance (--n / --batch: the other large-n sizes)
+        args.batch = args.batch if args.batch != 32 else 1
+        args.n = args.n if args.n != 2048 else 16384
+        args.families = "uniform"
         args.cpu_sample = min(args.cpu_sample, 1)
     if args.steps is None:
         args.steps = 1 if args.config == "K5" else 10

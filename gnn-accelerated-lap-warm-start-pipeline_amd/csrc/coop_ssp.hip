@@ -938,7 +938,8 @@ __global__ void __launch_bounds__(64) coop_ssp_kernel(CoopParams p)
     if (b >= p.first + p.count || b >= p.batch) return;
     int *hand = p.hand + (size_t)b * kHandInts;
     const int nf = hand[0];
-    if (nf <= 0 || hand[2] != 0) return;
+    const int f_first = hand[1];  // > 0: relaunched behind a path that jv_instance_kernel searched
+    if (nf <= 0 || hand[2] != 0 || hand[4] != 0 || hand[3] != 0 || f_first >= nf) return;
     const int n = p.n;
     const size_t o = (size_t)b * n;
 
@@ -976,9 +977,9 @@ __global__ void __launch_bounds__(64) coop_ssp_kernel(CoopParams p)
     const int *fr = p.fr + o;
 
     m.allow_xcd_stores = p.xcd_stores != 0;
-    int done = 0;
+    int done = f_first;
     m.setup_round();
-    for (int f = 0; f < nf && !m.err; ++f) {
+    for (int f = f_first; f < nf && !m.err; ++f) {
         const long long s_scan = m.scan_elems, s_init = m.init_elems;
         const int s_paths = m.paths, s_finds = m.finds, s_steps = m.scan_steps;
         const int start = uni(fr[f]);
@@ -1040,14 +1041,14 @@ __global__ void __launch_bounds__(64) coop_ssp_kernel(CoopParams p)
         hand[2] = m.err;
         hand[3] = m.bail_reason;
         long long *cs = p.cstats + (size_t)b * kCoopStats;
-        cs[0] = m.paths;
-        cs[1] = m.finds;
-        cs[2] = m.scan_steps;
-        cs[3] = m.scan_elems;
-        cs[4] = m.init_elems;
-        cs[5] = (long long)m.seq | (m.same_xcd ? (1ll << 40) : 0);
+        cs[0] += m.paths;
+        cs[1] += m.finds;
+        cs[2] += m.scan_steps;
+        cs[3] += m.scan_elems;
+        cs[4] += m.init_elems;
+        cs[5] = ((cs[5] & 0xffffffffffll) + (long long)m.seq) | (m.same_xcd ? (1ll << 40) : 0);
 #ifdef LAPWARM_COOP_STAMPS
-        for (int qd = 0; qd < 10; ++qd) cs[6 + qd] = m.stamps[qd];
+        for (int qd = 0; qd < 9; ++qd) cs[6 + qd] += m.stamps[qd];
 #endif
     } else if (m.err && m.lane == 0) {
         // a member other than the leader saw the error first: make sure it is not lost

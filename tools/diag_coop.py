@@ -24,8 +24,14 @@ else:
 torch.manual_seed(0)
 pipe = WarmStartPipeline(OneGNN(21, hidden=64, layers=2).eval(), "cuda:0")
 C = torch.from_numpy(Cs).cuda()
-u = C.min(dim=2).values.contiguous()          # row-minimum seeds (untrained-GNN quality)
-v = min_trick_device(C, u)
+if os.environ.get("DIAG_GNN", "0") == "1":      # the pipeline's own seeds: random-init OneGNN H=192 L=4 (bench.py)
+    torch.manual_seed(0)
+    pipe = WarmStartPipeline(OneGNN(21, hidden=192, layers=4).eval(), "cuda:0")
+    u, v = pipe.predict_batch(C)
+    u = u.to(torch.float64)
+else:
+    u = C.min(dim=2).values.contiguous()      # row-minimum seeds
+    v = min_trick_device(C, u)
 torch.cuda.synchronize()
 for rep in range(reps):
     t0 = time.perf_counter()
@@ -37,14 +43,14 @@ coop_paths = [int(s & 0xffffffff) if s >= 0 else -1 for s in st[:, 15]]
 reason = [int(s >> 32) if s >= 0 else -1 for s in st[:, 15]]
 print(f"n={n} B={B} {fam}: {dt*1e3:.2f} ms/batch  ret={sorted(set(ret.tolist()))} err={sorted(set(st[:,12].tolist()))}")
 print(f"   paths={st[:,4].tolist()[:8]} coop_paths={coop_paths[:8]} stop_reason={reason[:8]} steps={st[:,6].tolist()[:8]} "
-      f"finds={st[:,5].tolist()[:8]} rounds={[int(v & 0xffffffff) for v in st[:,16]][:8]} same_xcd={[int(v >> 40) for v in st[:,16]][:8]}")
+      f"finds={st[:,5].tolist()[:8]} handoffs={st[:,26].tolist()[:8]} rounds={[int(v & 0xffffffff) for v in st[:,16]][:8]} same_xcd={[int(v >> 40) for v in st[:,16]][:8]}")
 if st[0, 17:27].any():
     names = ["row wait", "emit", "stores", "poll", "post(no ev)", "post(multi ev)", "post(1 ev)", "-", "rounds", "-"]
     rounds = max(1, st[0, 25])
     print("   stamps b=0 (cycles per relax round): " + ", ".join(f"{nm}={st[0,17+k]/rounds:.0f}" for k, nm in enumerate(names) if nm != "-"))
     relax_cyc = st[0, 17:24].sum()
     print(f"   totals b=0 (Mcycles): relax rounds {relax_cyc/1e6:.0f}, collections {st[0,24]/1e6:.0f} ({st[0,24]/max(1,st[0,5]):.0f} each), "
-          f"path init+end {st[0,26]/1e6:.0f} ({st[0,26]/max(1,st[0,4]):.0f} per path); kernel wall {dt*1e3:.0f} ms")
+          f"paths searched by jv_instance_kernel between launches {st[0,26]}; kernel wall {dt*1e3:.0f} ms")
 tot_steps = st[:, 6].max()
 print(f"   slowest instance: {tot_steps} relax steps, {dt*1e6/max(1,tot_steps):.3f} us per step (whole batch time / max steps)")
 un, vn = u.cpu().numpy(), v.cpu().numpy()

@@ -3,7 +3,7 @@
 # A step that times out (124/137) stops the chain: no further GPU step after a killed one.
 set -u
 mkdir -p gpurun_out
-TAG=${TAG:-r02}
+TAG=${TAG:-r03}
 step() {  # name timeout cmd...
   local name=$1 tmo=$2; shift 2
   echo "=== $name" | tee -a gpurun_out/summary.log
@@ -25,7 +25,10 @@ for s in "$@"; do
     bench_serial) step bench_serial 400 python bench.py --steps 5 --warmup 2 --no-overlap --cpu-sample 0 --no-node-baseline ;;
     bench_k2) step bench_k2 300 python bench.py --config K2 --steps 10 --warmup 3 --cpu-sample 0 ;;
     bench_k4) step bench_k4 400 python bench.py --config K4 --steps 3 --warmup 1 --cpu-sample 0 ;;
-    bench_k5) step bench_k5 600 python bench.py --config K5 --steps 1 --warmup 1 --cpu-sample 0 ;;
+    bench_k5) step bench_k5 600 python bench.py --config K5 --steps 2 --warmup 1 --cpu-sample 1 ;;
+    bench_8192) step bench_8192 300 python bench.py --config K5 --n 8192 --batch 4 --steps 2 --warmup 1 --cpu-sample 1 ;;
+    prof_k5) export TMPDIR=/tmp; step prof_k5 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_k5 -o $TAG -- python3 bench.py --config K5 --steps 1 --warmup 1 --cpu-sample 0 ;;
+    coop_stamps) LAPWARM_HIP_LIB=$PWD/gnn-accelerated-lap-warm-start-pipeline_amd/liblapwarm_hip_coopstamps.so DIAG_CHECK=0 step coop_stamps 300 python tools/diag_coop.py 8192 1 uniform 2 ;;
     bench_inflight) step bench_inflight 400 python bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-node-baseline --inflight 8 ;;
     bench256) step bench256 300 python bench.py --steps 2 --warmup 1 --threads-hint 256 --cpu-sample 0 ;;
     bench1024) step bench1024 300 python bench.py --steps 2 --warmup 1 --threads-hint 1024 --cpu-sample 0 ;;
