@@ -415,8 +415,7 @@ struct Member {
             runp = pfp;
         }
         // classify the owned positions: strict event = undercuts everything before it, tie event = equals it
-        unsigned sb = 0;
-        bool tie = false;
+        unsigned sb = 0, tb = 0;
         int prevpos[CH];
         double prevval[CH];
 #pragma unroll
@@ -431,7 +430,7 @@ struct Member {
                         prevpos[r] = runp;
                         prevval[r] = runv;
                     } else {
-                        tie = true;
+                        tb |= 1u << r;
                     }
                 }
                 if (k == lo || dk[r] < runv) {
@@ -457,39 +456,140 @@ struct Member {
             }
         }
 
-        // ---- round B: did any member see a tie event?  (a tie changes the permutation of the TODO
-        // positions in a way that needs the whole ordered event list: not handled here)
-        const unsigned long long anytie_local = __ballot(tie);
+        // ---- round B: tie events.  A tie with the FINAL minimum (d == totv: nothing later undercuts it)
+        // is one more column for the SCAN list; the serial swaps of such ties (lapjv.cpp:165-167 behind
+        // the last strict event) are exactly the swaps of a relax step's events with hi = lo + 1, so they
+        // are exchanged and applied the same way: one event per member, the columns at order[lo+1 ..
+        // lo+4] as they stand AFTER the shift in the window.  (Seeds that went through float32 produce
+        // such a tie in ~0.3 % of the collections -- almost always exactly one.)  A tie with an
+        // intermediate minimum, several ties in one member, more than kWin ties or a tie inside the
+        // window end the cooperative search of this path (bail).
+        unsigned tf = 0;
+#pragma unroll
+        for (int r = 0; r < CH; ++r) tf |= (((tb >> r) & 1u) && dk[r] == totv) ? (1u << r) : 0u;
+        const bool early_local = __ballot((tb & ~tf) != 0u) != 0ull;
+        int cntf = 0;
+        unsigned t0a = 0, t0b = 0, t0c = 0;
+        {
+            const unsigned long long any = __ballot(tf != 0);
+            if (any) {
+#pragma unroll
+                for (int r = 0; r < CH; ++r) cntf += __popcll(__ballot((tf >> r) & 1u));
+                const int l = __builtin_ctzll(any);
+                const unsigned em = (unsigned)__builtin_amdgcn_readlane((int)tf, l);
+                const int r0 = __builtin_ctz(em);
+                int sj = jr[0], sy = yr[0], sp = pr[0];
+#pragma unroll
+                for (int qd = 1; qd < CH; ++qd) {
+                    if (r0 == qd) {
+                        sj = jr[qd];
+                        sy = yr[qd];
+                        sp = pr[qd];
+                    }
+                }
+                t0a = (unsigned)(base + l * CH + r0) | ((unsigned)__builtin_amdgcn_readlane(sj, l) << 16);
+                t0b = (unsigned)(__builtin_amdgcn_readlane(sy, l) + 1);
+                t0c = (unsigned)__builtin_amdgcn_readlane(sp, l);
+            }
+        }
+        hi = lo + 1;  // (the window below is order[hi .. hi+3])
+        if ((unsigned)(hi + kWin - 1 - base) < (unsigned)(P + kWin - 1)) {
+            const int L0 = (hi >= base) ? (hi - base) / CH : 0;
+            const int row = lane - L0;
+            if ((unsigned)row < 4u) {
+#pragma unroll
+                for (int r = 0; r < CH; ++r) {
+                    unsigned *d = wb + (row * CH + r) * kSlot;
+                    const bool sh = (sb >> r) & 1u;  // a strict event position: what the shift will leave there
+                    const double dv = sh ? prevval[r] : dk[r];
+                    d[0] = (unsigned)(sh ? pc[r] : jr[r]) | ((unsigned)(sh ? pq[r] : pr[r]) << 16);
+                    d[1] = (unsigned)((sh ? py[r] : yr[r]) + 1);
+                    d[2] = lo32(dv);
+                    d[3] = hi32(dv);
+                    d[4] = 0u;  // (the dual is not known for a shifted column yet: the adopter loads it)
+                    d[5] = 0u;
+                }
+            }
+        }
         ++seq;
-        publish((anytie_local ? 4u : 0u) | (err ? kFlagErr : 0u), 0, 0, 0, false);
-        if (!poll(NGm)) {
+        publish((early_local ? 4u : 0u) | (err ? kFlagErr : 0u) | ((unsigned)(cntf > 255 ? 255 : cntf) << 8), t0a, t0b, t0c, true);
+        if (!poll(NGm + kWinGran)) {
             err = 20;
             return kRcErr;
         }
         if (const int rc = check_flags(0, 0)) return rc;
+        int ntie = 0;
+        int tp_[kWin] = {0, 0, 0, 0}, tj_[kWin] = {0, 0, 0, 0}, ty_[kWin] = {0, 0, 0, 0}, tq_[kWin] = {0, 0, 0, 0};
         {
-            unsigned f = 0;
+            unsigned w0 = 0;
             if constexpr (kWideRec) {
                 const unsigned w = member_word(0);
-                if (lane < G) f = w & 4u;
+                if (lane < G) w0 = w;
             } else {
-                if (lane < NGm && (lane & (kK - 1)) == 0) f = gv[0] & 4u;
+                if (lane < NGm && (lane & (kK - 1)) == 0) w0 = gv[0];
             }
-            if (__ballot(f != 0)) {
-                bail_reason = 1;
+            const int cm = (int)((w0 >> 8) & 0xffu);
+            if (__ballot((w0 & 4u) != 0)) {
+                bail_reason = 1;  // a tie with an intermediate minimum
                 return kRcBail;
             }
+            unsigned long long mm = __ballot(cm > 0);
+            if (__ballot(cm > 1) || __popcll(mm) > kWin) {
+                bail_reason = 3;  // more final ties than one round carries
+                return kRcBail;
+            }
+            while (mm) {
+                const int ml = __builtin_ctzll(mm);
+                mm &= mm - 1;
+                const int gb = kWideRec ? ml * kK : ml;  // granule 0 of that member's record
+                const unsigned wa = rxu(gb + 1), wy = rxu(gb + 2), wq = rxu(gb + 3);
+                const int pp_ = (int)(wa & 0xffffu), jj_ = (int)(wa >> 16), yy_ = (int)wy - 1, qq_ = (int)wq;
+                if (ntie == 0) {
+                    tp_[0] = pp_, tj_[0] = jj_, ty_[0] = yy_, tq_[0] = qq_;
+                } else if (ntie == 1) {
+                    tp_[1] = pp_, tj_[1] = jj_, ty_[1] = yy_, tq_[1] = qq_;
+                } else if (ntie == 2) {
+                    tp_[2] = pp_, tj_[2] = jj_, ty_[2] = yy_, tq_[2] = qq_;
+                } else {
+                    tp_[3] = pp_, tj_[3] = jj_, ty_[3] = yy_, tq_[3] = qq_;
+                }
+                ++ntie;
+            }
+            if (ntie > 0) {
+                bool bad = tp_[0] <= lo + ntie;  // a tie inside the window [lo+1, lo+ntie]: the swaps are not independent
+#pragma unroll
+                for (int t = 0; t < kWin; ++t) {
+                    if (t < ntie)
+                        bad = bad || (unsigned)tp_[t] >= (unsigned)n || (unsigned)tj_[t] >= (unsigned)n || ty_[t] >= n ||
+                              (unsigned)tq_[t] >= (unsigned)n;
+                }
+                if (bad) {
+                    bail_reason = 3;
+                    return kRcBail;
+                }
+            }
         }
-        hi = lo + 1;
         level = totv;
         head_j = min_col;
         head_i = min_row;
         // the leader keeps the predecessor of every column that joins the SCAN list (final from here
         // on): the backtrack only ever follows those
         if (g == 0 && lane == 0) st_i32(pred + min_col, min_pred);
-        if (head_i < 0) {
-            target = head_j;  // the only minimum is a free column: the path ends here
-            return kRcTarget;
+        // the LAST free column of the SCAN list ends the path (lapjv.cpp:250-255)
+        {
+            int tg = (head_i < 0) ? head_j : -1, tgq = min_pred;
+#pragma unroll
+            for (int t = 0; t < kWin; ++t) {
+                if (t < ntie && ty_[t] < 0) {
+                    tg = tj_[t];
+                    tgq = tq_[t];
+                }
+            }
+            if (tg >= 0) {
+                if (g == 0 && lane == 0) st_i32(pred + tg, tgq);
+                target = tg;
+                return kRcTarget;
+            }
         }
         // tie-free: the serial swap sequence collapses to a shift, applied by the owners themselves
 #pragma unroll
@@ -521,6 +621,50 @@ struct Member {
             }
         }
         if (lane == 0) q[lo & (kQ - 1)] = make_int2(min_col, min_row);
+        // final ties: tie s swaps order[its position] with order[lo + 1 + s] (independent: no tie sits
+        // inside [lo+1, lo+ntie]); its column joins the SCAN list at the level, with the predecessor it had
+#pragma unroll
+        for (int t = 0; t < kWin; ++t) {
+            if (t < ntie) {
+                const unsigned w0 = rxu(NGm + kSlot * t);
+                const int a = (int)(w0 & 0xffffu), qa = (int)(w0 >> 16), ya = (int)rxu(NGm + kSlot * t + 1) - 1;
+                const double da = mk_f64(rxu(NGm + kSlot * t + 2), rxu(NGm + kSlot * t + 3));
+                if ((unsigned)a >= (unsigned)n || ya >= n || (unsigned)qa >= (unsigned)n) {
+                    err = 8;
+                    return kRcErr;
+                }
+                if ((unsigned)(tp_[t] - base) < (unsigned)P) {
+                    foreign_push(a);
+                    const double va = ld_f64(v + a);
+#pragma unroll
+                    for (int r = 0; r < CH; ++r) {
+                        if (b0 + r == tp_[t]) {
+                            jr[r] = a;
+                            yr[r] = ya;
+                            pr[r] = qa;
+                            dk[r] = da;
+                            vr[r] = va;
+                        }
+                    }
+                }
+                if ((unsigned)(lo + 1 + t - base) < (unsigned)P) {
+#pragma unroll
+                    for (int r = 0; r < CH; ++r) {
+                        if (b0 + r == lo + 1 + t) {
+                            jr[r] = tj_[t];
+                            yr[r] = ty_[t];
+                            pr[r] = tq_[t];
+                            dk[r] = totv;
+                        }
+                    }
+                }
+                if (lane == 0) {
+                    q[(lo + 1 + t) & (kQ - 1)] = make_int2(tj_[t], ty_[t]);
+                    if (g == 0) st_i32(pred + tj_[t], tq_[t]);
+                }
+            }
+        }
+        hi = lo + 1 + ntie;
         return kRcGo;
     }
 

@@ -9,8 +9,6 @@
 //   min-trick        scripts/gnn_benchmark.py:262 ; column minima gnn/features.py:218
 //   dual utilities   solvers/advanced_dual.py:14-63
 //   row features     gnn/features.py:161-243
-#include <stdlib.h>
-
 #include "device_utils.hpp"
 #include "jv_solver.hpp"
 
@@ -582,12 +580,9 @@ __device__ __forceinline__ void reduce_sum3_isum2(BlockCtx &bc, double &a, doubl
 }
 
 template <bool CACHE_E>
-__global__ void __launch_bounds__(kSweepThreads, 6) row_features_kernel(FeatureParams p, int npad,
-                                                                        const unsigned char *only_flagged)
+__global__ void __launch_bounds__(kSweepThreads, 6) row_features_kernel(FeatureParams p, int npad)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    // second launch behind row_features_wave_kernel: only the rows it could not finish
-    if (only_flagged && !only_flagged[(size_t)blockIdx.y * p.n + blockIdx.x]) return;
     BlockExchange *ex = reinterpret_cast<BlockExchange *>(smem);
     double *s = reinterpret_cast<double *>(smem + sizeof(BlockExchange));
     double *ev = s + npad;  // exp(-(x - lo)), kept between the two entropy passes when it fits
@@ -716,417 +711,6 @@ __global__ void __launch_bounds__(kSweepThreads, 6) row_features_kernel(FeatureP
         f[12] = (float)((double)(cnts >> 16) / m);
         for (int q = 0; q < 8; ++q) f[13 + q] = p.posenc[(size_t)i * 8 + q];
     }
-}
-
-
-// ------------------------------------------------------------------------------------------
-// Round 3: ONE WAVE PER ROW for n <= 4096.  The row lives in registers (n/64 elements per lane),
-// every reduction is a wave reduction, the selection histogram belongs to the wave -- no workgroup
-// barrier anywhere (the workgroup-per-row kernel above has ~16 per row and replicates its control
-// flow on four waves).  Same selection principle: counts over a monotone bucket map, so the values
-// found are the ones a sort would put at those ranks.  Oversized buckets are split once more over
-// the members' own range (ties of one value are recognised as such); a row that still has more
-// than 64 candidates in a sub-bucket is flagged and redone by row_features_kernel (fallback[]).
-// ------------------------------------------------------------------------------------------
-struct WaveSel {
-    unsigned hist[256];
-    double comb[16 + kSelList];
-    double list[2][kSelList];
-    double top[16];
-};
-
-__device__ __forceinline__ int wave_excl_scan_i32(int v, int lane, int *total)
-{
-    int incl = v;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        const int o = __shfl_up(incl, off, kWave);
-        if (lane >= off) incl += o;
-    }
-    *total = __shfl(incl, kWave - 1, kWave);
-    return incl - v;
-}
-
-// one histogram level over the elements selected by `sel` (bit e of the lane's mask); returns the
-// bin that holds rank `kk` (counted inside the selection), and that bin's count / elements below it
-// (bucket numbers packed four to a register: a byte array would take a register per element)
-template <int EPT>
-__device__ __forceinline__ void wave_hist_level(WaveSel *ws, const double (&x)[EPT], unsigned long long sel, int lane,
-                                                double lo, double scale, unsigned (&bk)[EPT / 4])
-{
-#pragma unroll
-    for (int q = 0; q < 4; ++q) ws->hist[4 * lane + q] = 0;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        if ((sel >> e) & 1ull) {
-            const int lb = lin_bucket(x[e], lo, scale);
-            bk[e >> 2] |= (unsigned)lb << ((e & 3) * 8);
-            atomicAdd(&ws->hist[lb], 1u);
-        }
-    }
-}
-template <int EPT>
-__device__ __forceinline__ int bucket_at(const unsigned (&bk)[EPT / 4], int e)
-{
-    return (int)((bk[e >> 2] >> ((e & 3) * 8)) & 255u);
-}
-
-// bin / rank-inside-bin / count / elements-below for one rank (all wave-uniform on return)
-__device__ __forceinline__ void wave_find_bin(const WaveSel *ws, int lane, int rank, int *bin, int *kk, int *cnt, int *below)
-{
-    int c[4], tot = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        c[q] = (int)ws->hist[4 * lane + q];
-        tot += c[q];
-    }
-    int total;
-    int ex = wave_excl_scan_i32(tot, lane, &total);
-    int hb = -1, hk = 0, hc = 0, hx = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (ex <= rank && rank < ex + c[q]) {
-            hb = 4 * lane + q;
-            hk = rank - ex;
-            hc = c[q];
-            hx = ex;
-        }
-        ex += c[q];
-    }
-    const unsigned long long m = __ballot(hb >= 0);
-    const int l = m ? __builtin_ctzll(m) : 0;
-    *bin = __builtin_amdgcn_readlane(hb, l);
-    *kk = __builtin_amdgcn_readlane(hk, l);
-    *cnt = __builtin_amdgcn_readlane(hc, l);
-    *below = __builtin_amdgcn_readlane(hx, l);
-}
-
-// Exact order statistics of the valid elements of x (bit e of `valid`): ranks rank[0..NT), ascending.
-// TOP: also the rank[0]+1 smallest values into ws->top (rank[0] <= 15), +inf beyond.
-// Returns false when a target still has more than kSelList candidates after two levels.
-template <int EPT, int NT, bool TOP>
-__device__ __forceinline__ bool wave_select(WaveSel *ws, const double (&x)[EPT], unsigned long long valid, int lane,
-                                            double lo, double hi, const int (&rank)[NT], double (&out)[NT])
-{
-    const double width = hi - lo;
-    const double scale = (width > 0.0 && width < pos_inf()) ? 255.0 / width : 0.0;
-    unsigned b1[EPT / 4];
-#pragma unroll
-    for (int e = 0; e < EPT / 4; ++e) b1[e] = 0;
-    wave_hist_level<EPT>(ws, x, valid, lane, lo, scale, b1);
-    int bin[NT], kk[NT], cnt[NT], below[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) wave_find_bin(ws, lane, rank[t], &bin[t], &kk[t], &cnt[t], &below[t]);
-    // second level for oversized bins (per target; the histogram is reused)
-    bool narrowed[NT], alleq[NT];
-    double eqval[NT], lo2[NT], scale2[NT];
-    int bin2[NT];
-    bool ok = true;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        narrowed[t] = false;
-        alleq[t] = false;
-        eqval[t] = 0.0;
-        lo2[t] = 0.0;
-        scale2[t] = 0.0;
-        bin2[t] = 0;
-        if (cnt[t] > kSelList) {  // uniform
-            unsigned long long mem = 0;
-            double mn = pos_inf(), mx = -pos_inf();
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                if (((valid >> e) & 1ull) && bucket_at<EPT>(b1, e) == bin[t]) {
-                    mem |= 1ull << e;
-                    mn = dmin(mn, x[e]);
-                    mx = (x[e] > mx) ? x[e] : mx;
-                }
-            }
-            mn = wave_min(mn);
-            mx = wave_max(mx);
-            if (mn == mx) {
-                alleq[t] = true;
-                eqval[t] = mn;
-            } else {
-                const double w2 = mx - mn;
-                const double sc2 = (w2 > 0.0 && w2 < pos_inf()) ? 255.0 / w2 : 0.0;
-                unsigned b2[EPT / 4];
-#pragma unroll
-                for (int e = 0; e < EPT / 4; ++e) b2[e] = 0;
-                wave_hist_level<EPT>(ws, x, mem, lane, mn, sc2, b2);
-                int bb, k2, c2, bl2;
-                wave_find_bin(ws, lane, kk[t], &bb, &k2, &c2, &bl2);
-                narrowed[t] = true;
-                lo2[t] = mn;
-                scale2[t] = sc2;
-                bin2[t] = bb;
-                kk[t] = k2;
-                below[t] += bl2;
-                cnt[t] = c2;
-                if (c2 > kSelList) {
-                    // one value many times?
-                    double m2 = pos_inf(), x2 = -pos_inf();
-#pragma unroll
-                    for (int e = 0; e < EPT; ++e) {
-                        if (((mem >> e) & 1ull) && bucket_at<EPT>(b2, e) == bb) {
-                            m2 = dmin(m2, x[e]);
-                            x2 = (x[e] > x2) ? x[e] : x2;
-                        }
-                    }
-                    m2 = wave_min(m2);
-                    x2 = wave_max(x2);
-                    if (m2 == x2) {
-                        alleq[t] = true;
-                        eqval[t] = m2;
-                    } else {
-                        ok = false;
-                    }
-                }
-            }
-        }
-    }
-    if (!ok) return false;
-    if (TOP && below[0] > 15) return false;  // (cannot happen: rank[0] <= 15)
-    // gather the candidates of every target (and, for TOP, everything below target 0's bin)
-    int lc[NT], lowc = 0;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) lc[t] = 0;
-    const int off0 = TOP ? below[0] : 0;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const bool v = (valid >> e) & 1ull;
-        bool anyhit = false;
-        bool memb[NT];
-        bool isbelow = false;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int be = bucket_at<EPT>(b1, e);
-            bool m = v && be == bin[t];
-            int sb = 0;
-            if (narrowed[t]) {  // uniform per target
-                sb = lin_bucket(x[e], lo2[t], scale2[t]);
-                m = m && sb == bin2[t];
-            }
-            memb[t] = m && !alleq[t];
-            anyhit = anyhit || memb[t];
-            if (TOP && t == 0) {
-                isbelow = v && (be < bin[0] || (be == bin[0] && narrowed[0] && sb < bin2[0]));
-                anyhit = anyhit || isbelow;
-            }
-        }
-        if (__ballot(anyhit) == 0ull) continue;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const unsigned long long mm = __ballot(memb[t]);
-            if (mm) {
-                const int q = lc[t] + __popcll(mm & ((1ull << lane) - 1ull));
-                if (memb[t]) {
-                    if (t == 0)
-                        ws->comb[off0 + q] = x[e];
-                    else
-                        ws->list[t - 1][q] = x[e];
-                }
-                lc[t] += __popcll(mm);
-            }
-        }
-        if (TOP) {
-            const unsigned long long mb = __ballot(isbelow);
-            if (mb) {
-                const int q = lowc + __popcll(mb & ((1ull << lane) - 1ull));
-                if (isbelow) ws->comb[q] = x[e];
-                lowc += __popcll(mb);
-            }
-        }
-    }
-    // rank the candidates by counting
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        out[t] = eqval[t];
-        if (!alleq[t]) {
-            const int c = cnt[t];
-            const double *L = (t == 0) ? ws->comb + off0 : ws->list[t - 1];
-            const double a = (lane < c) ? L[lane] : pos_inf();
-            int r = 0;
-            for (int q = 0; q < c; ++q) {
-                const double o = L[q];
-                r += (o < a || (o == a && q < lane)) ? 1 : 0;
-            }
-            const unsigned long long hit = __ballot(lane < c && r == kk[t]);
-            out[t] = readlane_f64(a, hit ? __builtin_ctzll(hit) : 0);
-        }
-    }
-    if (TOP) {
-        const int base0 = below[0];
-        const int m = base0 + (alleq[0] ? 0 : cnt[0]);
-        const int l0 = lane, l1 = lane + kWave;
-        const double a0 = (l0 < m) ? ws->comb[l0] : pos_inf();
-        const double a1 = (l1 < m) ? ws->comb[l1] : pos_inf();
-        int r0 = 0, r1 = 0;
-        for (int q = 0; q < m; ++q) {
-            const double o = ws->comb[q];
-            r0 += (o < a0 || (o == a0 && q < l0)) ? 1 : 0;
-            r1 += (o < a1 || (o == a1 && q < l1)) ? 1 : 0;
-        }
-        if (l0 > rank[0] && l0 < 16) ws->top[l0] = pos_inf();
-        if (l0 < m && r0 <= rank[0]) ws->top[r0] = a0;
-        if (l1 < m && r1 <= rank[0]) ws->top[r1] = a1;
-        if (alleq[0] && l0 >= base0 && l0 <= rank[0]) ws->top[l0] = eqval[0];
-    }
-    return true;
-}
-
-template <int EPT>
-__global__ void __launch_bounds__(256, (EPT <= 32) ? 3 : 2) row_features_wave_kernel(FeatureParams p, unsigned char *fallback)
-{
-    __shared__ WaveSel sel_s[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = p.n;
-    const long long rowid = (long long)blockIdx.x * 4 + wave;
-    if (rowid >= (long long)p.batch * n) return;  // (whole wave; nothing below synchronises the workgroup)
-    const int b = (int)(rowid / n), i = (int)(rowid % n);
-    WaveSel *ws = &sel_s[wave];
-    const double *row = p.C + (size_t)rowid * n;
-    const double *cm = p.colmin + (size_t)b * n;
-
-    // element e of the lane = column (e/2 * 64 + lane) * 2 + (e & 1): 16-byte loads, n even
-    double x[EPT];
-    unsigned long long valid = 0;
-    double lo = pos_inf(), hi = -pos_inf(), sum = 0.0;
-#pragma unroll
-    for (int q = 0; q < EPT / 2; ++q) {
-        const int j = (q * 64 + lane) * 2;
-        if (j < n) {
-            const double2 t = *reinterpret_cast<const double2 *>(row + j);
-            x[2 * q] = t.x;
-            x[2 * q + 1] = t.y;
-            valid |= 3ull << (2 * q);
-        } else {
-            x[2 * q] = 0.0;
-            x[2 * q + 1] = 0.0;
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        if ((valid >> e) & 1ull) {
-            lo = dmin(lo, x[e]);
-            hi = (x[e] > hi) ? x[e] : hi;
-            sum += x[e];
-        }
-    }
-    lo = wave_min(lo);
-    hi = wave_max(hi);
-    sum = wave_sum_f64(sum);
-    const double mean = sum / n;
-    const double thresh = lo * 1.1;
-
-    // second pass (see row_features_kernel for the closed form of the entropy)
-    double sq = 0.0, esum = 0.0, tsum = 0.0;
-    int near = 0, colbest = 0, mcnt = 0;
-    bool mid = false;
-    const double tau = 1e-6 * (double)n;
-#pragma unroll
-    for (int q = 0; q < EPT / 2; ++q) {
-        const int j = (q * 64 + lane) * 2;
-        if (j < n) {
-            const double2 c2 = *reinterpret_cast<const double2 *>(cm + j);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const double xv = x[2 * q + h];
-                const double dlt = xv - mean;
-                sq += dlt * dlt;
-                const double xl = xv - lo;
-                const double ev = exp(-xl);
-                esum += ev;
-                if (ev > 0.0) {
-                    tsum += ev * xl;
-                    mcnt += 1;
-                    mid = mid || (ev < tau);
-                }
-                near += (xv <= thresh) ? 1 : 0;
-                colbest += (xv == (h ? c2.y : c2.x)) ? 1 : 0;
-            }
-        }
-    }
-    sq = wave_sum_f64(sq);
-    esum = wave_sum_f64(esum);
-    tsum = wave_sum_f64(tsum);
-    near = wave_sum_i32(near);
-    colbest = wave_sum_i32(colbest);
-    mcnt = wave_sum_i32(mcnt);
-    const double denom = esum + kFeatEps;
-    double ent;
-    if (__ballot(mid) == 0ull) {
-        ent = tsum / denom + (esum / denom) * log(denom) - (double)mcnt * kFeatEps;
-    } else {
-        const double rdenom = 1.0 / denom;
-        ent = 0.0;
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            if ((valid >> e) & 1ull) {
-                const double pj = exp(-(x[e] - lo)) * rdenom;
-                ent += pj * log(pj + kFeatEps);
-            }
-        }
-        ent = -wave_sum_f64(ent);
-    }
-
-    const size_t orow = (size_t)rowid;
-    const int rk[3] = {(n < 16 ? n : 16) - 1, (n - 1) >> 1, n >> 1};
-    double sel[3];
-    if (!wave_select<EPT, 3, true>(ws, x, valid, lane, lo, hi, rk, sel)) {
-        if (lane == 0) fallback[orow] = 1;
-        return;
-    }
-    const double med = (n & 1) ? sel[2] : (sel[1] + sel[2]) / 2.0;
-    const int kk = (n < 10) ? n : 10;
-    double gap = 0.0, kmean, kstd;
-    {
-        if (n >= 2) gap = ws->top[1] - ws->top[0];
-        double acc = 0.0;
-        for (int q = 0; q < kk; ++q) acc += ws->top[q];
-        kmean = acc / kk;
-        double a2 = 0.0;
-        for (int q = 0; q < kk; ++q) {
-            const double dq = ws->top[q] - kmean;
-            a2 += dq * dq;
-        }
-        kstd = sqrt(a2 / kk);
-    }
-    const float topv = (lane < 16) ? (float)ws->top[lane] : 0.0f;  // (read before the second selection reuses the lists)
-    // median absolute deviation
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) x[e] = fabs(x[e] - med);
-    const double dlo = fabs(lo - med), dhi = fabs(hi - med);
-    const double dmax = (dlo > dhi) ? dlo : dhi;
-    const int rd[2] = {(n - 1) >> 1, n >> 1};
-    double dsel[2];
-    if (!wave_select<EPT, 2, false>(ws, x, valid, lane, 0.0, dmax, rd, dsel)) {
-        if (lane == 0) fallback[orow] = 1;
-        return;
-    }
-    double mad = (n & 1) ? dsel[1] : (dsel[0] + dsel[1]) / 2.0;
-    if (mad < kFeatEps) mad = kFeatEps;
-    double competition = 0.0, difficulty = 0.0;
-    if (n >= 2) {
-        competition = gap / ((hi - lo) + kFeatEps);
-        difficulty = 1.0 / ((hi - lo) / (double)(n - 1) + kFeatEps);
-    }
-    const double m = (n > 1) ? (double)n : 1.0;
-    float fv = (float)lo;
-    fv = (lane == 1) ? (float)hi : fv;
-    fv = (lane == 2) ? (float)mean : fv;
-    fv = (lane == 3) ? (float)sqrt(sq / n) : fv;
-    fv = (lane == 4) ? (float)mad : fv;
-    fv = (lane == 5) ? (float)ent : fv;
-    fv = (lane == 6) ? (float)gap : fv;
-    fv = (lane == 7) ? (float)competition : fv;
-    fv = (lane == 8) ? (float)kmean : fv;
-    fv = (lane == 9) ? (float)kstd : fv;
-    fv = (lane == 10) ? (float)difficulty : fv;
-    fv = (lane == 11) ? (float)((double)near / m) : fv;
-    fv = (lane == 12) ? (float)((double)colbest / m) : fv;
-    if (lane >= 13 && lane < 21) fv = p.posenc[(size_t)i * 8 + (lane - 13)];
-    if (lane < 21) p.feat[orow * 21 + lane] = fv;
-    if (p.topk && lane < 16) p.topk[orow * 16 + lane] = topv;
-    if (lane == 0) fallback[orow] = 0;
 }
 
 }  // namespace
@@ -1264,34 +848,20 @@ hipError_t launch_row_features(const FeatureParams &p, hipStream_t stream)
 {
     if (p.n > 16384 || p.n < 1) return hipErrorInvalidValue;
     const int npad = (p.n + 1) & ~1;
-    static const int wave_rows = [] {
-        const char *e = getenv("LAPWARM_FEATURES_WAVE");
-        return (e && e[0] == '0') ? 0 : 1;
-    }();
-    // n <= 4096, even: one wave per row first (no workgroup barriers); the workgroup-per-row kernel then
-    // redoes the rows it flagged (heavy ties inside a sub-bucket, infinite entries)
-    const unsigned char *only = nullptr;
-    if (wave_rows && p.fallback && p.n % 2 == 0 && p.n <= 4096) {
-        const long long rows = (long long)p.batch * p.n;
-        const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-        if (p.n <= 512)
-            hipLaunchKernelGGL(row_features_wave_kernel<8>, grid, block, 0, stream, p, p.fallback);
-        else if (p.n <= 1024)
-            hipLaunchKernelGGL(row_features_wave_kernel<16>, grid, block, 0, stream, p, p.fallback);
-        else if (p.n <= 2048)
-            hipLaunchKernelGGL(row_features_wave_kernel<32>, grid, block, 0, stream, p, p.fallback);
-        else
-            hipLaunchKernelGGL(row_features_wave_kernel<64>, grid, block, 0, stream, p, p.fallback);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        only = p.fallback;
-    }
-    const size_t lds = sizeof(BlockExchange) + sizeof(double) * (size_t)npad + sizeof(SelectState) +
+    // exp(-(x - lo)) is no longer kept in LDS between the entropy passes: the closed form needs it
+    // once, the element-wise path recomputes it, and the 8 n bytes saved let 6-7 workgroups share a
+    // CU (measured: 1.29 -> 1.02 ms for 32 x 2048 rows together with the 6-waves-per-SIMD bound)
+    const bool cache = false;
+    const size_t lds = sizeof(BlockExchange) + sizeof(double) * (size_t)npad * (cache ? 2 : 1) + sizeof(SelectState) +
                        (size_t)npad;  // + one bucket byte per element
-    const void *fn = reinterpret_cast<const void *>(row_features_kernel<false>);
+    const void *fn = cache ? reinterpret_cast<const void *>(row_features_kernel<true>)
+                           : reinterpret_cast<const void *>(row_features_kernel<false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(row_features_kernel<false>, dim3(p.n, p.batch), dim3(kSweepThreads), lds, stream, p, npad, only);
+    if (cache)
+        hipLaunchKernelGGL(row_features_kernel<true>, dim3(p.n, p.batch), dim3(kSweepThreads), lds, stream, p, npad);
+    else
+        hipLaunchKernelGGL(row_features_kernel<false>, dim3(p.n, p.batch), dim3(kSweepThreads), lds, stream, p, npad);
     return hipGetLastError();
 }
 

@@ -141,7 +141,6 @@ struct FeatureParams {
     const float *posenc;   // [n][8] host-computed table
     float *feat;           // [batch][n][21]
     float *topk;           // [batch][n][16] ascending, +inf padded, or null
-    unsigned char *fallback;  // [batch][n] scratch: rows the wave-per-row kernel leaves to the workgroup-per-row one
 };
 hipError_t launch_row_features(const FeatureParams &p, hipStream_t stream);
 

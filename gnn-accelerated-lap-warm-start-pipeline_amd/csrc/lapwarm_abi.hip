@@ -369,10 +369,8 @@ int lapwarm_row_features_batched(const double *C, int batch, int n, const float 
     Carver c{reinterpret_cast<unsigned char *>(workspace), 0};
     double *partial = c.take<double>(bn * (size_t)colmin_chunks(n, batch));
     double *colmin = c.take<double>(bn);
-    unsigned char *fallback = reinterpret_cast<unsigned char *>(c.take<double>(bn));  // (the row-partial block: free here)
     HIP_TRY(launch_colmin(C, n, batch, nullptr, colmin, partial, stream));
     FeatureParams fp;
-    fp.fallback = fallback;
     fp.C = C;
     fp.n = n;
     fp.batch = batch;
