@@ -130,6 +130,7 @@ struct Member {
     int paths, finds, scan_steps;
     int err, bail_reason;
     bool same_xcd, allow_xcd_stores;
+    int win_t, win_e;  // this lane's window slot / word when it stores a window granule (lanes 8 .. 31)
 #ifdef LAPWARM_COOP_STAMPS
     long long stamps[10];
 #endif
@@ -148,10 +149,13 @@ struct Member {
         w = (lane == 3) ? w3 : w;
         bool mine = lane < kK;
         int idx = g * kK + lane;
-        if (with_window) {
+        // (uniform: does this member write any window slot this round?  most members do not)
+        const bool win_here = with_window && ((unsigned)(hi + kWin - 1 - base) < (unsigned)(P + kWin - 1) ||
+                                              (g == G - 1 && hi + kWin > n));
+        if (win_here) {
             const int wl = lane - 8;
             if ((unsigned)wl < (unsigned)kWinGran) {
-                const int t = wl / kSlot, e = wl - t * kSlot;
+                const int t = win_t, e = win_e;  // (lane - 8) / kSlot, (lane - 8) % kSlot: fixed per lane
                 const int pos = hi + t;
                 mine = (pos < n) ? ((unsigned)(pos - base) < (unsigned)P) : (g == G - 1);
                 // staged by lane (pos - base) / CH as its position (pos - base) % CH; stage row 0 is lane L0
@@ -272,7 +276,7 @@ struct Member {
     // vmcnt retires in order, an earlier request would sit in front of the loads the step waits for.
     __device__ __forceinline__ void prefetch_row(int row_i)
     {
-        if ((unsigned)row_i >= (unsigned)n) return;
+        if ((unsigned)row_i >= (unsigned)n || (n & 1)) return;  // (16-byte requests: rows of an odd n are only 8-byte aligned)
         const double *row = C + (size_t)row_i * n;
 #pragma unroll
         for (int qd = 0; qd < (CH + 1) / 2; ++qd) {
@@ -683,8 +687,10 @@ struct Member {
             // SCAN / READY positions are not relaxed: point them at the head's own entry (one line every
             // lane reads anyway) instead of a column whose line nobody prefetched
             const int k = b0 + r;
+            // (jr[] only ever holds columns that were range-checked when they arrived: path start, shift,
+            // adoption from a validated record)
             const int jc = ((k >= hi) & (k < n)) ? jr[r] : head_j;
-            c[r] = row[umin_u32((unsigned)jc, (unsigned)(n - 1))];
+            c[r] = row[jc];
         }
         const double c_head = row[head_j];
         const double v_head = ld_f64(v + head_j);
@@ -784,15 +790,21 @@ struct Member {
             CSTAMP(tr3);
             CSTAMP_ADD(3, tr3, tr2);
             CSTAMP_INC(8);
-            if (const int rc = check_flags(1, 28)) return rc;
-            // event counts, on the lanes that hold word 1 of a member record
+            // event counts and flags, on the lanes that hold word 1 of a member record
             // (more than 16 members: on lane m for member m, fetched by a cross-lane read)
             int cm = 0;
-            if constexpr (kWideRec) {
-                const unsigned w = member_word(1);
-                if (lane < G) cm = (int)((w >> 20) & 0xffu);
-            } else {
-                if (lane < NGm && (lane & (kK - 1)) == 1) cm = (int)((gv[0] >> 20) & 0xffu);
+            {
+                unsigned w1 = 0;
+                if constexpr (kWideRec) {
+                    const unsigned w = member_word(1);
+                    if (lane < G) w1 = w;
+                } else {
+                    if (lane < NGm && (lane & (kK - 1)) == 1) w1 = gv[0];
+                }
+                if (__ballot((w1 >> 28) & 3u)) {  // rare: somebody reports an error or asks to stop
+                    if (const int rc = check_flags(1, 28)) return rc;
+                }
+                cm = (int)((w1 >> 20) & 0xffu);
             }
             const unsigned long long evl = __ballot(cm > 0);
             if (evl == 0ull) {
@@ -1121,6 +1133,8 @@ __global__ void __launch_bounds__(64) coop_ssp_kernel(CoopParams p)
     const int *fr = p.fr + o;
 
     m.allow_xcd_stores = p.xcd_stores != 0;
+    m.win_t = ((int)threadIdx.x - 8) / kSlot;
+    m.win_e = ((int)threadIdx.x - 8) % kSlot;
     int done = f_first;
     m.setup_round();
     for (int f = f_first; f < nf && !m.err; ++f) {

@@ -386,6 +386,30 @@ def test_cooperative_kernel_forced_on_small_sizes_native_sweep():
     assert "bad=0" in proc.stdout.splitlines()[-1]
 
 
+def test_cooperative_kernel_odd_size(torch_cuda):
+    """An odd n above the threshold (rows only 8-byte aligned: the 16-byte row prefetch is off, the last
+    member is partly empty): bit-exact with equal counters."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    from gnn.features import min_trick_device
+    from oracle import jv
+    B, n = 2, 4611
+    Cs = np.stack([np.random.RandomState(7 + i).uniform(0, 1, (n, n)) for i in range(B)])
+    pipe = WarmStartPipeline(OneGNN(21, hidden=64, layers=2).eval(), "cuda:0")
+    C = torch.from_numpy(Cs).cuda()
+    u = C.min(dim=2).values.contiguous()
+    v = min_trick_device(C, u)
+    x, y, ret, stats = pipe.seeded_batch(C, u, v)
+    torch.cuda.synchronize()
+    st = stats.cpu().numpy()
+    assert (st[:, 15] >= 0).all()
+    un, vn = u.cpu().numpy(), v.cpu().numpy()
+    for b in range(B):
+        r, xo, yo, so = jv.seeded_raw(Cs[b], un[b], vn[b])
+        assert r == int(ret[b]) == 0 and np.array_equal(xo, x[b].cpu().numpy()) and np.array_equal(yo, y[b].cpu().numpy())
+        assert st[b, 6] == so["scan_steps"] and st[b, 5] == so["finds"] and st[b, 4] == so["paths"]
+
+
 @pytest.mark.parametrize("fams", [("uniform", "sparse"), ("tie", "clustered")])
 def test_cooperative_kernel_at_its_threshold_size(torch_cuda, fams):
     """n = 4608 (the first sizes whose solver state leaves LDS run the cooperative kernel, 9 members
