@@ -40,6 +40,9 @@ for s in "$@"; do
              step pmc_write 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o $TAG -- python3 bench.py --steps 1 --warmup 1 --cpu-sample 0 --no-node-baseline --no-overlap ;;
     pmc_sq)  export TMPDIR=/tmp
              step pmc_sq 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc_sq -o $TAG -- python3 bench.py --steps 1 --warmup 1 --cpu-sample 0 --no-node-baseline --no-overlap ;;
+    pmc_k5)  export TMPDIR=/tmp
+             step pmc_k5_fetch 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_k5_fetch -o $TAG -- python3 bench.py --config K5 --n 8192 --batch 1 --steps 1 --warmup 1 --cpu-sample 0 --no-overlap
+             step pmc_k5_sq 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d gpurun_out/pmc_k5_sq -o $TAG -- python3 bench.py --config K5 --n 8192 --batch 1 --steps 1 --warmup 1 --cpu-sample 0 --no-overlap ;;
     *) echo "unknown step $s" ;;
   esac
 done
