@@ -14,9 +14,11 @@
 //
 // What is NOT handled here ends the cooperative phase for that instance at a path boundary
 // ("bail"): x, y, v are only written at the end of a path, so the state in global memory is that of
-// the path's start and jv_instance_kernel (phase 2) resumes from free row `hand[1]`.  Bails today:
-// a minima collection with a tie event (never on continuous random costs),
-// a SCAN list longer than the replicated queue.
+// the path's start; jv_instance_kernel searches that ONE path (phase 3) and this kernel is launched
+// again behind it (launch_solver enqueues a fixed number of such pairs; phase 2 finishes whatever is
+// left).  Bails today: a minima collection with several ties of which one has an intermediate
+// minimum, several final ties in one member or more than four in all, a tie inside the window, a
+// SCAN list longer than the replicated queue.
 //
 // Happens-before (every cross-member datum; "round" = publish + poll of all members' records):
 //   v[], y[] (path-constant)      written in path_end / backtrack, drained, then the ack / go round;
@@ -471,17 +473,23 @@ struct Member {
         unsigned tf = 0;
 #pragma unroll
         for (int r = 0; r < CH; ++r) tf |= (((tb >> r) & 1u) && dk[r] == totv) ? (1u << r) : 0u;
-        const bool early_local = __ballot((tb & ~tf) != 0u) != 0ull;
-        int cntf = 0;
+        // (a single tie with an INTERMEDIATE minimum is handled too: it swaps order[t] with order[lo+1]
+        // like a final tie would, but its column stays a TODO column at its own distance)
+        int cntf = 0, cnte = 0;
+        bool first_early = false;
         unsigned t0a = 0, t0b = 0, t0c = 0;
         {
-            const unsigned long long any = __ballot(tf != 0);
+            const unsigned long long any = __ballot(tb != 0);
             if (any) {
 #pragma unroll
-                for (int r = 0; r < CH; ++r) cntf += __popcll(__ballot((tf >> r) & 1u));
+                for (int r = 0; r < CH; ++r) {
+                    cntf += __popcll(__ballot((tf >> r) & 1u));
+                    cnte += __popcll(__ballot(((tb & ~tf) >> r) & 1u));
+                }
                 const int l = __builtin_ctzll(any);
-                const unsigned em = (unsigned)__builtin_amdgcn_readlane((int)tf, l);
+                const unsigned em = (unsigned)__builtin_amdgcn_readlane((int)tb, l);
                 const int r0 = __builtin_ctz(em);
+                first_early = !(((unsigned)__builtin_amdgcn_readlane((int)tf, l) >> r0) & 1u);
                 int sj = jr[0], sy = yr[0], sp = pr[0];
 #pragma unroll
                 for (int qd = 1; qd < CH; ++qd) {
@@ -516,13 +524,16 @@ struct Member {
             }
         }
         ++seq;
-        publish((early_local ? 4u : 0u) | (err ? kFlagErr : 0u) | ((unsigned)(cntf > 255 ? 255 : cntf) << 8), t0a, t0b, t0c, true);
+        publish((first_early ? 4u : 0u) | (err ? kFlagErr : 0u) | ((unsigned)(cntf > 255 ? 255 : cntf) << 8) |
+                    ((unsigned)(cnte > 255 ? 255 : cnte) << 16),
+                t0a, t0b, t0c, true);
         if (!poll(NGm + kWinGran)) {
             err = 20;
             return kRcErr;
         }
         if (const int rc = check_flags(0, 0)) return rc;
         int ntie = 0;
+        bool early1 = false;
         int tp_[kWin] = {0, 0, 0, 0}, tj_[kWin] = {0, 0, 0, 0}, ty_[kWin] = {0, 0, 0, 0}, tq_[kWin] = {0, 0, 0, 0};
         {
             unsigned w0 = 0;
@@ -532,10 +543,16 @@ struct Member {
             } else {
                 if (lane < NGm && (lane & (kK - 1)) == 0) w0 = gv[0];
             }
-            const int cm = (int)((w0 >> 8) & 0xffu);
-            if (__ballot((w0 & 4u) != 0)) {
-                bail_reason = 1;  // a tie with an intermediate minimum
-                return kRcBail;
+            const int cmf = (int)((w0 >> 8) & 0xffu), cme = (int)((w0 >> 16) & 0xffu);
+            const int cm = cmf + cme;
+            const int early_total = wave_sum_i32(cme);
+            if (early_total > 0) {
+                // exactly one tie in the whole collection, and it is the early one: handled below
+                if (early_total != 1 || __ballot(cmf > 0)) {
+                    bail_reason = 1;  // ties with an intermediate minimum beyond the single-tie case
+                    return kRcBail;
+                }
+                early1 = true;
             }
             unsigned long long mm = __ballot(cm > 0);
             if (__ballot(cm > 1) || __popcll(mm) > kWin) {
@@ -558,6 +575,10 @@ struct Member {
                     tp_[3] = pp_, tj_[3] = jj_, ty_[3] = yy_, tq_[3] = qq_;
                 }
                 ++ntie;
+            }
+            if (early1 && tp_[0] == lo + 1) {
+                early1 = false;  // order[lo+1] swapped with itself
+                ntie = 0;
             }
             if (ntie > 0) {
                 bool bad = tp_[0] <= lo + ntie;  // a tie inside the window [lo+1, lo+ntie]: the swaps are not independent
@@ -584,7 +605,7 @@ struct Member {
             int tg = (head_i < 0) ? head_j : -1, tgq = min_pred;
 #pragma unroll
             for (int t = 0; t < kWin; ++t) {
-                if (t < ntie && ty_[t] < 0) {
+                if (!early1 && t < ntie && ty_[t] < 0) {
                     tg = tj_[t];
                     tgq = tq_[t];
                 }
@@ -625,6 +646,64 @@ struct Member {
             }
         }
         if (lane == 0) q[lo & (kQ - 1)] = make_int2(min_col, min_row);
+        if (early1) {
+            // the single early tie: order[tp] <-> order[lo+1]; the tie column stays a TODO column with its own
+            // distance, which only its owner knows: one more round carries it
+            const unsigned w0 = rxu(NGm);
+            const int a = (int)(w0 & 0xffffu), qa = (int)(w0 >> 16), ya = (int)rxu(NGm + 1) - 1;
+            const double da = mk_f64(rxu(NGm + 2), rxu(NGm + 3));
+            if ((unsigned)a >= (unsigned)n || ya >= n || (unsigned)qa >= (unsigned)n) {
+                err = 8;
+                return kRcErr;
+            }
+            double dt_own = 0.0;
+#pragma unroll
+            for (int r = 0; r < CH; ++r) {
+                if (b0 + r == tp_[0]) dt_own = dk[r];
+            }
+            const int own_lane = uni((tp_[0] - base) / CH);
+            const bool own_here = (unsigned)(tp_[0] - base) < (unsigned)P;
+            const double dt_pub = own_here ? readlane_f64(dt_own, own_here ? own_lane : 0) : 0.0;
+            ++seq;
+            publish(lo32(dt_pub), hi32(dt_pub), 0, (err ? kFlagErr : 0u) << 28, false);
+            if (!poll(NGm)) {
+                err = 20;
+                return kRcErr;
+            }
+            if (const int rc = check_flags(3, 28)) return rc;
+            const int om = tp_[0] / P;  // the member that owns the tie's position
+            const double d_tie = mk_f64(rxu(om * kK), rxu(om * kK + 1));
+            if ((unsigned)(tp_[0] - base) < (unsigned)P) {
+                foreign_push(a);
+                const double va = ld_f64(v + a);
+#pragma unroll
+                for (int r = 0; r < CH; ++r) {
+                    if (b0 + r == tp_[0]) {
+                        jr[r] = a;
+                        yr[r] = ya;
+                        pr[r] = qa;
+                        dk[r] = da;
+                        vr[r] = va;
+                    }
+                }
+            }
+            if ((unsigned)(lo + 1 - base) < (unsigned)P) {
+                foreign_push(tj_[0]);
+                const double vt = ld_f64(v + tj_[0]);
+#pragma unroll
+                for (int r = 0; r < CH; ++r) {
+                    if (b0 + r == lo + 1) {
+                        jr[r] = tj_[0];
+                        yr[r] = ty_[0];
+                        pr[r] = tq_[0];
+                        dk[r] = d_tie;
+                        vr[r] = vt;
+                    }
+                }
+            }
+            hi = lo + 1;
+            return kRcGo;
+        }
         // final ties: tie s swaps order[its position] with order[lo + 1 + s] (independent: no tie sits
         // inside [lo+1, lo+ntie]); its column joins the SCAN list at the level, with the predecessor it had
 #pragma unroll
