@@ -1285,9 +1285,24 @@ __global__ void __launch_bounds__(64) coop_ssp_kernel(CoopParams p)
         cs[4] += m.init_elems;
         cs[5] = ((cs[5] & 0xffffffffffll) + (long long)m.seq) | (m.same_xcd ? (1ll << 40) : 0);
 #ifdef LAPWARM_COOP_STAMPS
-        for (int qd = 0; qd < 9; ++qd) cs[6 + qd] += m.stamps[qd];
+        for (int qd = 0; qd < 6; ++qd) cs[6 + qd] += m.stamps[qd];
 #endif
-    } else if (m.err && m.lane == 0) {
+    }
+#ifdef LAPWARM_COOP_STAMPS
+    // imbalance between the members of an instance: smallest / largest total of the poll segment and of
+    // everything else in a relax round (slots 12 .. 15; reset by phase 1)
+    if (m.lane == 0) {
+        unsigned long long *cs = reinterpret_cast<unsigned long long *>(p.cstats + (size_t)b * kCoopStats);
+        const unsigned long long poll_c = (unsigned long long)m.stamps[3];
+        const unsigned long long work_c = (unsigned long long)(m.stamps[0] + m.stamps[1] + m.stamps[2] + m.stamps[4] +
+                                                                m.stamps[5] + m.stamps[6]);
+        atomicMax(&cs[12], poll_c);
+        atomicMax(&cs[13], work_c);
+        atomicMax(&cs[14], ~poll_c);  // (max of the complement = min)
+        atomicMax(&cs[15], ~work_c);
+    }
+#endif
+    if (g != 0 && m.err && m.lane == 0) {
         // a member other than the leader saw the error first: make sure it is not lost
         atomicMax(&hand[4], m.err);
     }

@@ -43,14 +43,14 @@ coop_paths = [int(s & 0xffffffff) if s >= 0 else -1 for s in st[:, 15]]
 reason = [int(s >> 32) if s >= 0 else -1 for s in st[:, 15]]
 print(f"n={n} B={B} {fam}: {dt*1e3:.2f} ms/batch  ret={sorted(set(ret.tolist()))} err={sorted(set(st[:,12].tolist()))}")
 print(f"   paths={st[:,4].tolist()[:8]} coop_paths={coop_paths[:8]} stop_reason={reason[:8]} steps={st[:,6].tolist()[:8]} "
-      f"finds={st[:,5].tolist()[:8]} handoffs={st[:,26].tolist()[:8]} rounds={[int(v & 0xffffffff) for v in st[:,16]][:8]} same_xcd={[int(v >> 40) for v in st[:,16]][:8]}")
-if st[0, 17:27].any():
-    names = ["row wait", "emit", "stores", "poll", "post(no ev)", "post(multi ev)", "post(1 ev)", "-", "rounds", "-"]
-    rounds = max(1, st[0, 25])
-    print("   stamps b=0 (cycles per relax round): " + ", ".join(f"{nm}={st[0,17+k]/rounds:.0f}" for k, nm in enumerate(names) if nm != "-"))
-    relax_cyc = st[0, 17:24].sum()
-    print(f"   totals b=0 (Mcycles): relax rounds {relax_cyc/1e6:.0f}, collections {st[0,24]/1e6:.0f} ({st[0,24]/max(1,st[0,5]):.0f} each), "
-          f"paths searched by jv_instance_kernel between launches {st[0,26]}; kernel wall {dt*1e3:.0f} ms")
+      f"finds={st[:,5].tolist()[:8]} handoffs={(st[:,26] if not st[0,17:23].any() else st[:,26]*0-1).tolist()[:8]} rounds={[int(v & 0xffffffff) for v in st[:,16]][:8]} same_xcd={[int(v >> 40) for v in st[:,16]][:8]}")
+if st[0, 17:23].any():  # -DLAPWARM_COOP_STAMPS build: s_memtime ticks of instance 0's leader, summed over the run
+    names = ["row wait", "emit", "staging+publish", "poll", "post (no event)", "post (several events)"]
+    print("   leader stamps (M ticks over the run): " + ", ".join(f"{nm}={st[0,17+k]/1e6:.0f}" for k, nm in enumerate(names)))
+    mx_poll, mx_work = int(st[0, 23]), int(st[0, 24])
+    mn_poll, mn_work = (~int(st[0, 25])) & (2**64 - 1), (~int(st[0, 26])) & (2**64 - 1)
+    print(f"   members of instance 0 (M ticks over the run): poll min {mn_poll/1e6:.0f} max {mx_poll/1e6:.0f}; "
+          f"stamped rest of a relax round min {mn_work/1e6:.0f} max {mx_work/1e6:.0f}")
 tot_steps = st[:, 6].max()
 print(f"   slowest instance: {tot_steps} relax steps, {dt*1e6/max(1,tot_steps):.3f} us per step (whole batch time / max steps)")
 un, vn = u.cpu().numpy(), v.cpu().numpy()
