@@ -295,15 +295,20 @@ def run_rank(args):
     u_k2 = None
     if args.config == "K2":
         _, u_k2, _, _ = pipe.optimal_duals_batch(C)  # "oracle u": not part of the timed step
-    overlap = (not args.no_overlap) and u_k2 is None
+    overlap = not args.no_overlap
     solver_ms = []
+    k2_predict = None
+    if u_k2 is not None:
+        from gnn.features import min_trick_device, row_features_device
+
+        def k2_predict(Cb):                           # K2's dense stages: features + col-min, given duals
+            row_features_device(Cb)
+            return u_k2, min_trick_device(Cb, u_k2)
 
     def solve_local():
-        if u_k2 is not None:
-            from gnn.features import min_trick_device, row_features_device
-            feat, _ = row_features_device(C)          # K2 times features + col-min + seeded JV
-            v = min_trick_device(C, u_k2)
-            x, y, ret, stats = pipe.seeded_batch(C, u_k2, v)
+        if u_k2 is not None and not overlap:
+            u, v = k2_predict(C)                      # K2 times features + col-min + seeded JV
+            x, y, ret, stats = pipe.seeded_batch(C, u, v)
             return {"x": x, "y": y, "ret": ret, "stats": stats, "u": u_k2, "v": v}
         if overlap:
             # solve what was submitted during the previous step; submit this step's dense stages
@@ -320,7 +325,7 @@ def run_rank(args):
         torch.cuda.synchronize(dev)
 
     if overlap:
-        pipe.pipeline_submit(C)  # primes the pipeline (untimed, like the warm-up steps)
+        pipe.pipeline_submit(C, k2_predict)  # primes the pipeline (untimed, like the warm-up steps)
     out, elapsed = run_sharded(solve_local, args.steps, args.warmup, distributed=distributed,
                                gather_on_host=(args.backend != "nccl"), device_sync=device_sync,
                                after_step=after_step)
@@ -368,7 +373,9 @@ def run_rank(args):
                 "n": n,
                 "parallelism": "batch-sharded x%d, one %s gather of assignments" % (
                     world, "RCCL" if args.backend == "nccl" else args.backend),
-                "stage_overlap": ("two HIP streams: dense sweeps + OneGNN of step k+1 beside the solver of step k"
+                "stage_overlap": (("two HIP streams: row features + min-trick of step k+1 beside the solver of step k"
+                                   if u_k2 is not None else
+                                   "two HIP streams: dense sweeps + OneGNN of step k+1 beside the solver of step k")
                                   if overlap else "none (stages back to back on one stream)"),
                 "solver_threads_hint": args.threads_hint,
                 "solver_helper_workgroups": helpers,

@@ -169,15 +169,17 @@ class WarmStartPipeline:
         return self._s_pred, self._s_solve
 
     @torch.inference_mode()
-    def pipeline_submit(self, C: torch.Tensor):
-        """Enqueue features + OneGNN + min-trick for `C` on the prediction stream."""
+    def pipeline_submit(self, C: torch.Tensor, predict=None):
+        """Enqueue features + OneGNN + min-trick for `C` on the prediction stream.  `predict(C) -> (u, v)`
+        replaces the model-based prediction (K2: given duals, features + min-trick only)."""
         s_pred, _ = self._streams()
         s_pred.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s_pred):
-            u, v = self.predict_batch(C)
+            u, v = (predict or self.predict_batch)(C)
             ev = torch.cuda.Event()
             ev.record(s_pred)
         self._pending = (C, u, v, ev)
+        self._predict = predict
 
     @torch.inference_mode()
     def pipeline_step(self, C_next: Optional[torch.Tensor] = None, eps: float = 1e-12,
@@ -202,7 +204,7 @@ class WarmStartPipeline:
         for t in (x, y, ret) + ((stats,) if stats is not None else ()):
             t.record_stream(torch.cuda.current_stream(self.device))
         if C_next is not None:
-            self.pipeline_submit(C_next)
+            self.pipeline_submit(C_next, getattr(self, "_predict", None))
         return {"x": x, "y": y, "ret": ret, "stats": stats, "u": u, "v": v, "done": done}
 
     def pipeline_drain(self):
