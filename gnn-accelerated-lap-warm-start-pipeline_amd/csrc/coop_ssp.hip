@@ -43,8 +43,11 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) unsigned int gu32;
 #define LAPWARM_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
-constexpr int kK = 4;      // granules per member record
-constexpr int kEmax = 2;   // tie events a member publishes per round (2 granules each)
+constexpr int kK = 4;      // granules per member record (collection / path rounds)
+constexpr int kKr = 2;     // ... of a relax round: ONE tie event per member and round.  Every granule load of a
+                           // poll costs ~0.3 us per round (hop_bench: 32 members, 64 / 128 / 192 granules: 1.27 /
+                           // 1.57 / 1.88 us), so the round that runs once per relax step polls as little as it can
+constexpr int kEmax = 1;   // tie events a member publishes per relax round (2 granules each)
 constexpr int kWin = 4;    // window: events applied per round = columns at order[hi .. hi+3] published per round
 constexpr int kSlot = 6;   // granules per window slot: column | predecessor << 16, matched row + 1, distance, dual
 constexpr int kWinGran = kSlot * kWin;
@@ -116,6 +119,17 @@ struct Member {
     int *x, *y, *pred;
     unsigned long long *mail;  // [2][NGtot]
     int G, g, lane, base, b0, NGm, NGtot;
+    // geometry of the current round inside a buffer laid out [relax records: 2G][window][other records: 4G]:
+    // granules per record, first granule of the record region, of the window.  A poll's index space is
+    // "records, then window"; relax rounds are physically contiguous, the others take the window from the front
+    int rk, rbase, wphys;
+    __device__ __forceinline__ void round_kind(bool relax_round)
+    {
+        rk = relax_round ? kKr : kK;
+        rbase = relax_round ? 0 : kKr * G + kWinGran;
+        wphys = kKr * G;
+        NGm = rk * G;
+    }
     int2 *q;       // LDS: replicated SCAN queue
     unsigned gv[NL];  // payloads of the round just polled: granule i sits in lane i % 64 of gv[i / 64]
     int2 *lj;      // LDS: (column, matched row) of this member's positions during a collection
@@ -149,8 +163,8 @@ struct Member {
         w = (lane == 1) ? w1 : w;
         w = (lane == 2) ? w2 : w;
         w = (lane == 3) ? w3 : w;
-        bool mine = lane < kK;
-        int idx = g * kK + lane;
+        bool mine = lane < rk;
+        int idx = rbase + g * rk + lane;
         // (uniform: does this member write any window slot this round?  most members do not)
         const bool win_here = with_window && ((unsigned)(hi + kWin - 1 - base) < (unsigned)(P + kWin - 1) ||
                                               (g == G - 1 && hi + kWin > n));
@@ -164,7 +178,7 @@ struct Member {
                 const int lp = pos - base, L0 = (hi >= base) ? (hi - base) / CH : 0;
                 const bool owned = (pos < n) && ((unsigned)lp < (unsigned)P);
                 w = owned ? wb[((lp / CH - L0) * CH + lp % CH) * kSlot + e] : 0u;
-                idx = NGm + wl;
+                idx = wphys + wl;
             }
         }
         if (mine) {
@@ -180,6 +194,7 @@ struct Member {
     __device__ __forceinline__ bool setup_round()
     {
         same_xcd = false;
+        round_kind(false);
         const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xfu;
         ++seq;
         publish(xcc | 0x100u, 0, 0, 0, false);
@@ -208,10 +223,13 @@ struct Member {
             for (int qd = 0; qd < NL; ++qd) {
                 const int idx = qd * 64 + lane;
                 val[qd] = 0;
-                if (idx < need) {
-                    const unsigned long long w = ld_gran(buf + idx);
-                    val[qd] = (unsigned)w;
-                    ok &= (unsigned)(w >> 32) == seq;
+                if (qd * 64 < need) {  // (uniform: a relax round needs fewer loads than a collection round)
+                    if (idx < need) {
+                        const int phys = (idx < NGm) ? rbase + idx : wphys + (idx - NGm);
+                        const unsigned long long w = ld_gran(buf + phys);
+                        val[qd] = (unsigned)w;
+                        ok &= (unsigned)(w >> 32) == seq;
+                    }
                 }
             }
             if (__all(ok)) {
@@ -242,7 +260,7 @@ struct Member {
     // lane m < G: word `slot` of member m's record
     __device__ __forceinline__ unsigned member_word(int slot) const
     {
-        const int idx = lane * kK + slot;
+        const int idx = lane * rk + slot;
         const unsigned a = (unsigned)__shfl((int)gv[0], idx & 63, kWave);
         if constexpr (kWideRec) {
             const unsigned b = (unsigned)__shfl((int)gv[1], idx & 63, kWave);
@@ -260,7 +278,7 @@ struct Member {
             const unsigned w = member_word(slot);
             if (lane < G) f = (w >> shift) & 3u;
         } else {
-            if (lane < NGm && (lane & (kK - 1)) == slot) f = (gv[0] >> shift) & 3u;
+            if (lane < NGm && (lane & (rk - 1)) == slot) f = (gv[0] >> shift) & 3u;
         }
         if (__ballot((f & kFlagErr) != 0)) {
             if (!err) err = 21;  // another member reported an error
@@ -336,6 +354,7 @@ struct Member {
     // ---------------------------------------------------------------- minima collection (lapjv.cpp:153-171, :243-256)
     __device__ __forceinline__ int collect(int &target)
     {
+        round_kind(false);
         ready = lo;
         finds++;
         double tv = pos_inf();
@@ -798,7 +817,7 @@ struct Member {
             // ---- this member's pending tie events, in position order
             CSTAMP(tr0);
             int cnt = 0;
-            unsigned e0a = 0, e0b = 0, e1a = 0, e1b = 0;
+            unsigned e0a = 0, e0b = 0;
             unsigned long long any = __ballot(evm != 0);  // (94% of the member-rounds: none)
             if (any) {
 #pragma unroll
@@ -823,13 +842,8 @@ struct Member {
                         const unsigned yv = (unsigned)(__builtin_amdgcn_readlane(sy, l) + 1);
                         const unsigned pos = (unsigned)(base + l * CH + r);
                         const unsigned wa = pos | (j << 16);
-                        if (emitted == 0) {
-                            e0a = wa;
-                            e0b = yv;
-                        } else {
-                            e1a = wa;
-                            e1b = yv;
-                        }
+                        e0a = wa;
+                        e0b = yv;
                         ++emitted;
                     }
                 }
@@ -837,6 +851,7 @@ struct Member {
             e0b |= (unsigned)(cnt > 255 ? 255 : cnt) << 20;
             e0b |= (err ? kFlagErr : 0u) << 28;
             ++seq;
+            round_kind(true);
             CSTAMP(tr1);
             CSTAMP_ADD(1, tr1, tr0);
             // ---- the columns at order[hi .. hi+3] (what this round's events displace), with their
@@ -859,7 +874,7 @@ struct Member {
                     }
                 }
             }
-            publish(e0a, e0b, e1a, e1b, true);
+            publish(e0a, e0b, 0, 0, true);
             CSTAMP(tr2);
             CSTAMP_ADD(2, tr2, tr1);
             if (!poll(NGm + kWinGran)) {
@@ -870,16 +885,10 @@ struct Member {
             CSTAMP_ADD(3, tr3, tr2);
             CSTAMP_INC(8);
             // event counts and flags, on the lanes that hold word 1 of a member record
-            // (more than 16 members: on lane m for member m, fetched by a cross-lane read)
             int cm = 0;
             {
-                unsigned w1 = 0;
-                if constexpr (kWideRec) {
-                    const unsigned w = member_word(1);
-                    if (lane < G) w1 = w;
-                } else {
-                    if (lane < NGm && (lane & (kK - 1)) == 1) w1 = gv[0];
-                }
+                unsigned w1 = 0;  // (2 granules per member: up to 32 members sit in gv[0])
+                if (lane < NGm && (lane & 1) == 1) w1 = gv[0];
                 if (__ballot((w1 >> 28) & 3u)) {  // rare: somebody reports an error or asks to stop
                     if (const int rc = check_flags(1, 28)) return rc;
                 }
@@ -894,7 +903,7 @@ struct Member {
             const int first_l = __builtin_ctzll(evl);
             if ((evl & (evl - 1)) == 0ull && __builtin_amdgcn_readlane(cm, first_l) == 1) {
                 // ---- exactly one tie event in the whole step (60% of the steps that have any)
-                const int gb = kWideRec ? first_l * kK : first_l - 1;  // first granule of that member's record
+                const int gb = first_l - 1;  // first granule of that member's record
                 const unsigned wa = rxu(gb), wbv = rxu(gb + 1);
                 const int ep = (int)(wa & 0xffffu), ej = (int)(wa >> 16), ey = (int)(wbv & 0xfffffu) - 1;
                 const unsigned w0 = rxu(NGm);
@@ -958,12 +967,12 @@ struct Member {
                 while (mm && take < kWin && !blocked) {
                     const int ml = __builtin_ctzll(mm);  // lane holding word 1 of that member's record
                     mm &= mm - 1;
-                    const int m = kWideRec ? ml : (ml >> 2);
+                    const int m = ml >> 1;
                     const int c_m = __builtin_amdgcn_readlane(cm, ml);
                     const int pub = (c_m < kEmax) ? c_m : kEmax;
                     for (int e = 0; e < pub && take < kWin; ++e) {
-                        const unsigned wa = rxu(m * kK + 2 * e);
-                        const unsigned wbv = rxu(m * kK + 2 * e + 1);
+                        const unsigned wa = rxu(m * kKr + 2 * e);
+                        const unsigned wbv = rxu(m * kKr + 2 * e + 1);
                         const int pp_ = (int)(wa & 0xffffu), jj_ = (int)(wa >> 16), yy_ = (int)(wbv & 0xfffffu) - 1;
                         if (take == 0) {
                             ep0 = pp_, ej0 = jj_, ey0 = yy_;
@@ -1103,6 +1112,7 @@ struct Member {
     // ---------------------------------------------------------------- path end (lapjv.cpp:270-276, :302-314)
     __device__ __forceinline__ int path_end(int target, int start)
     {
+        round_kind(false);
         // dual update of the READY columns: v[j] += d[j] - level.  Positions below `ready` hold the
         // column that joined the SCAN list there and the level it joined at.
 #pragma unroll
@@ -1190,8 +1200,8 @@ __global__ void __launch_bounds__(64) coop_ssp_kernel(CoopParams p)
     m.lane = threadIdx.x;
     m.base = g * Member<CH, NL>::P;
     m.b0 = m.base + m.lane * CH;
-    m.NGm = G * kK;
-    m.NGtot = G * kK + kWinGran;
+    m.NGtot = G * (kK + kKr) + kWinGran;
+    m.round_kind(false);
     m.mail = p.mail + (size_t)b * 2 * m.NGtot;
     m.q = q_s;
     m.lj = lj_s;
@@ -1343,7 +1353,7 @@ int coop_members(int n)
     return (n + 64 * ch - 1) / (64 * ch);
 }
 
-size_t coop_mail_granules(int n) { return 2 * ((size_t)coop_members(n) * kK + kWinGran); }
+size_t coop_mail_granules(int n) { return 2 * ((size_t)coop_members(n) * (kK + kKr) + kWinGran); }
 
 bool coop_enabled(int n)
 {
@@ -1367,7 +1377,7 @@ hipError_t launch_coop(const CoopParams &p_in, hipStream_t stream)
     CoopParams p = p_in;
     const int ch = coop_ch(p.n);
     p.G = coop_members(p.n);
-    const int ng = p.G * kK + kWinGran;
+    const int ng = p.G * kK + kWinGran;  // the largest poll: a collection's round B
     static const int xcd_stores = [] {
         const char *e = getenv("LAPWARM_COOP_XCD_STORES");
         return (e && e[0] == '0') ? 0 : 1;
