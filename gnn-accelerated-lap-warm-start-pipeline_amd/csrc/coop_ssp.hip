@@ -255,14 +255,20 @@ struct Member {
             return (unsigned)__builtin_amdgcn_readlane((int)gv[NL - 1], i - 128);
         }
     }
-    // the records fill granules 0 .. G*kK-1: one register up to 16 members, two up to 32
-    static constexpr bool kWideRec = NL > 2;
+    // the records fill granules 0 .. G*rk-1: one register while that is at most 64 granules (16 members of
+    // a collection round), two beyond.  Wave-uniform, and decided from the member count, not from NL:
+    // 17 .. 26 members poll two registers (NL = 2) as well, and their records do cross into the second.
+    __device__ __forceinline__ bool wide_rec() const
+    {
+        if constexpr (NL < 2) return false;
+        return NGm > kWave;
+    }
     // lane m < G: word `slot` of member m's record
     __device__ __forceinline__ unsigned member_word(int slot) const
     {
         const int idx = lane * rk + slot;
         const unsigned a = (unsigned)__shfl((int)gv[0], idx & 63, kWave);
-        if constexpr (kWideRec) {
+        if constexpr (NL >= 2) {
             const unsigned b = (unsigned)__shfl((int)gv[1], idx & 63, kWave);
             return (idx < 64) ? a : b;
         }
@@ -274,7 +280,7 @@ struct Member {
     {
         // (looked at on the lanes that hold that granule: no cross-lane traffic)
         unsigned f = 0;
-        if constexpr (kWideRec) {
+        if (wide_rec()) {
             const unsigned w = member_word(slot);
             if (lane < G) f = (w >> shift) & 3u;
         } else {
@@ -556,7 +562,8 @@ struct Member {
         int tp_[kWin] = {0, 0, 0, 0}, tj_[kWin] = {0, 0, 0, 0}, ty_[kWin] = {0, 0, 0, 0}, tq_[kWin] = {0, 0, 0, 0};
         {
             unsigned w0 = 0;
-            if constexpr (kWideRec) {
+            const bool wide = wide_rec();
+            if (wide) {
                 const unsigned w = member_word(0);
                 if (lane < G) w0 = w;
             } else {
@@ -581,7 +588,7 @@ struct Member {
             while (mm) {
                 const int ml = __builtin_ctzll(mm);
                 mm &= mm - 1;
-                const int gb = kWideRec ? ml * kK : ml;  // granule 0 of that member's record
+                const int gb = wide ? ml * kK : ml;  // granule 0 of that member's record
                 const unsigned wa = rxu(gb + 1), wy = rxu(gb + 2), wq = rxu(gb + 3);
                 const int pp_ = (int)(wa & 0xffffu), jj_ = (int)(wa >> 16), yy_ = (int)wy - 1, qq_ = (int)wq;
                 if (ntie == 0) {
@@ -1343,8 +1350,12 @@ int coop_ch(int n)
     // better, as long as a lane's positions fit the register file (16 positions = ~250 VGPRs).
     if (n <= 512) return 1;
     if (n <= 1024) return 2;
-    if (n <= 2048) return 4;
-    return 8;  // measured: n = 8192 1.36 s with 8 (16 members), 1.64 s with 16, 1.50 s with 4; n = 16384 4.03 s with 8, 4.78 s with 16
+    // Measured with one event per member in a 2-granule relax record (a relax round polls 2G + 24 granules:
+    // one load per lane up to 20 members, two up to 32): n = 4608 x 8 467 ms with 4 positions per lane
+    // (18 members) against 508 ms with 8; n = 8192 1.13 s with 4 (32 members), 1.21 s with 8, 1.59 s with 16;
+    // n = 16384 3.88 s with 8 (32 members), 4.75 s with 16.
+    if (n <= 8192) return 4;
+    return 8;
 }
 
 int coop_members(int n)

@@ -4,6 +4,7 @@ on the same seeded inputs.  Integer results bit-exact; float32 model outputs wit
 north-star tolerance 1e-5."""
 import os
 import subprocess
+import sys
 from pathlib import Path
 
 import numpy as np
@@ -386,14 +387,18 @@ def test_cooperative_kernel_forced_on_small_sizes_native_sweep():
     assert "bad=0" in proc.stdout.splitlines()[-1]
 
 
-def test_cooperative_kernel_odd_size(torch_cuda):
-    """An odd n above the threshold (rows only 8-byte aligned: the 16-byte row prefetch is off, the last
-    member is partly empty): bit-exact with equal counters."""
+@pytest.mark.parametrize("n", [4611, 9216])
+def test_cooperative_kernel_member_counts(torch_cuda, n):
+    """n = 4611: an odd n above the threshold (rows only 8-byte aligned: the 16-byte row prefetch is off,
+    the last member is partly empty; 19 members of 256 positions).  n = 9216: 18 members of 512 positions
+    -- between 17 and 26 members a collection round's records no longer fit one 64-lane register while
+    the poll still takes two loads per lane (the case a round-3 build got wrong: error -137 for every
+    size from 8193 to 13312).  Bit-exact with equal counters."""
     torch = torch_cuda
     from gnn import OneGNN, WarmStartPipeline
     from gnn.features import min_trick_device
     from oracle import jv
-    B, n = 2, 4611
+    B = 2
     Cs = np.stack([np.random.RandomState(7 + i).uniform(0, 1, (n, n)) for i in range(B)])
     pipe = WarmStartPipeline(OneGNN(21, hidden=64, layers=2).eval(), "cuda:0")
     C = torch.from_numpy(Cs).cuda()
@@ -410,10 +415,48 @@ def test_cooperative_kernel_odd_size(torch_cuda):
         assert st[b, 6] == so["scan_steps"] and st[b, 5] == so["finds"] and st[b, 4] == so["paths"]
 
 
+_FORCED_COOP = r"""
+import sys, numpy as np, torch
+sys.path[:0] = [%r, %r]
+from gnn import OneGNN, WarmStartPipeline
+from gnn.features import min_trick_device
+from oracle import jv
+from lap import _hip
+n = int(sys.argv[1])
+assert _hip.load().lapwarm_coop_members(n) == int(sys.argv[2]), _hip.load().lapwarm_coop_members(n)
+Cs = np.stack([np.random.RandomState(11 + i).uniform(0, 1, (n, n)) for i in range(2)])
+pipe = WarmStartPipeline(OneGNN(21, hidden=64, layers=2).eval(), "cuda:0")
+C = torch.from_numpy(Cs).cuda()
+u = C.min(dim=2).values.contiguous()
+v = min_trick_device(C, u)
+x, y, ret, stats = pipe.seeded_batch(C, u, v)
+torch.cuda.synchronize()
+st = stats.cpu().numpy()
+assert (st[:, 15] >= 0).all()
+for b in range(2):
+    r, xo, yo, so = jv.seeded_raw(Cs[b], u[b].cpu().numpy(), v[b].cpu().numpy())
+    assert r == int(ret[b]) == 0 and np.array_equal(xo, x[b].cpu().numpy()) and np.array_equal(yo, y[b].cpu().numpy())
+    assert st[b, 6] == so["scan_steps"] and st[b, 5] == so["finds"] and st[b, 4] == so["paths"]
+print("forced-coop ok")
+"""
+
+
+@pytest.mark.parametrize("n,members", [(1024, 8), (3072, 12), (4096, 16)])
+def test_cooperative_kernel_forced_member_counts(n, members):
+    """Member counts the default plan never produces above its threshold -- 8 members of 128 positions
+    (one granule load per lane), 12 and 16 members of 256 (two loads, records within one register) --
+    forced on below the threshold in a child process (the switch is read once per process)."""
+    env = dict(os.environ, LAPWARM_COOP_MIN_N="1")
+    script = _FORCED_COOP % (str(ROOT), str(ROOT / "gnn-accelerated-lap-warm-start-pipeline_amd"))
+    proc = subprocess.run([sys.executable, "-c", script, str(n), str(members)], capture_output=True, text=True,
+                          timeout=600, env=env, cwd=str(ROOT))
+    assert proc.returncode == 0 and "forced-coop ok" in proc.stdout, (proc.stdout[-2000:], proc.stderr[-3000:])
+
+
 @pytest.mark.parametrize("fams", [("uniform", "sparse"), ("tie", "clustered")])
 def test_cooperative_kernel_at_its_threshold_size(torch_cuda, fams):
-    """n = 4608 (the first sizes whose solver state leaves LDS run the cooperative kernel, 9 members
-    of 512 positions): continuous costs stay in it for every path; sparse / tie / clustered costs
+    """n = 4608 (the first sizes whose solver state leaves LDS run the cooperative kernel, 18 members
+    of 256 positions): continuous costs stay in it for every path; sparse / tie / clustered costs
     produce tie collections, where it stops and jv_instance_kernel resumes.  Assignments bit-exact
     and the path / collection / relax-step / element counters equal to the oracle's either way --
     the counters of the two kernels add up to the serial algorithm's."""

@@ -252,16 +252,17 @@ def test_solver_lds_plan_fits_the_cu_for_every_size():
 
 def test_cooperative_plan_per_size():
     """Host side of the cooperative shortest-path kernel (no GPU needed): it is planned from the size
-    where the solver state leaves one CU's LDS, with at most 32 members of 64 x {1,2,4,8} positions
+    where the solver state leaves one CU's LDS, with at most 32 members of 64 x {4,8} positions
     that cover the row, and the solver workspace grows by its mailbox + hand-over block there."""
     from lap import _hip
     lib = _hip.load()
     assert lib.lapwarm_coop_members(2048) == 0 and lib.lapwarm_coop_members(4096) == 0  # single-workgroup kernel
     assert lib.lapwarm_coop_members(4427) == 0 and lib.lapwarm_coop_members(4428) > 0
-    assert lib.lapwarm_coop_members(8192) == 16 and lib.lapwarm_coop_members(16384) == 32
-    for n in (4428, 4608, 5000, 8191, 8192, 12000, 16384):
+    assert lib.lapwarm_coop_members(8192) == 32 and lib.lapwarm_coop_members(16384) == 32
+    for n in (4428, 4608, 5000, 8191, 8192, 8193, 9216, 12000, 16384):
         g = lib.lapwarm_coop_members(n)
-        assert 1 <= g <= 32 and g * 64 * 8 >= n > (g - 1) * 64 * 8, (n, g)
+        per_lane = 4 if n <= 8192 else 8
+        assert 1 <= g <= 32 and g * 64 * per_lane >= n > (g - 1) * 64 * per_lane, (n, g)
         assert lib.lapwarm_solver_uses_helpers(n) == 0  # the helper workgroups belong to the other kernel
     assert lib.lapwarm_coop_members(0) == 0 and lib.lapwarm_coop_members(20000) == 0
     # workspace: monotone in the batch and large enough for the global solver state the hand-over uses
