@@ -75,6 +75,14 @@ struct alignas(16) Ctrl {
     int free_pos[2];  // smallest position of a tie event whose column is FREE, per step parity
                       // (INT_MAX: none); lets the ordered replay skip the y[] lookup per event
 };
+// Augmenting row reduction with candidate lists: the loop state wave 0 hands to the workgroup when a row
+// needs the full scan.  It lives in Ctrl::rec, which only the shortest-path phase uses (a Ctrl that grew by
+// these 28 bytes shifted every LDS array of the seeded kernel and cost K3 2 %: 76.6 -> 78.4 ms).
+struct ArrState {
+    unsigned arr_current, arr_rr;
+    int arr_new_free, arr_fwd, arr_iters, arr_fast, arr_err;
+};
+static_assert(sizeof(ArrState) <= sizeof(EventSlot) * 2 * kRecEvents, "ArrState is overlaid on Ctrl::rec");
 
 constexpr int kSentinelIdx = 0x7ffffffe;  // the LARGE sentinel of the ARR scan (index -1 in the reference)
 constexpr int kEmptyIdx = 0x7fffffff;
@@ -1315,8 +1323,198 @@ struct Solver {
         return nf;
     }
 
-    // lapjv.cpp:76-149.  One augmenting-row-reduction sweep over fr[0..n_free).
-    __device__ __forceinline__ int cold_arr_sweep(int n_free)
+    // ---- candidate lists of the augmenting row reduction
+    // 99 % of the ARR iterations of a uniform instance continue with the row the last one displaced
+    // (tools/micro/arr_chain_stats.c): the iterations form one dependent chain of ~1.4e5 row scans at
+    // n = 2048, each a 16-KiB row from beyond the L2 plus a workgroup reduction (~2 us).  The chain
+    // itself cannot be shortened, but an iteration can: v[] only ever DECREASES during the row reduction
+    // (lapjv.cpp:117, v2 >= v1), so c[i][j] - v[j] only grows.  For row i keep the kArrListD smallest
+    // c - v of each of 64 column classes (j mod 64) as candidates, and tau_i = the smallest value left
+    // out (the minimum over the classes of their (kArrListD+1)-th smallest).  Whenever the second
+    // smallest candidate is < tau_i at today's v, no column outside the list can be among the two
+    // smallest (it was >= tau_i when the list was built and has only grown), so one wave finds
+    // (v1, j1, v2, j2) from 128 entries without a workgroup barrier; ties at equal values are
+    // inside the list and resolved by column index exactly as the serial scan does.  Otherwise the whole
+    // workgroup scans the row as before and wave 0 rebuilds that row's list at the current v.
+    // Measured on the CPU (tools/micro/arr_lists_sim.py, n = 1024): uniform 0.01 %, sparse
+    // 0.4 %, tie 0.01 %, noisy_linear 1.4 % of the iterations take the full scan.
+    static constexpr int kArrListD = 2;
+    static constexpr int kArrListLen = kArrListD * kWave;
+    static_assert(kArrListLen == kArrListEntries, "workspace layout");
+
+    // One wave builds the list of row i at the current v (entries: raw cost + column, -1 = none).
+    __device__ __forceinline__ void arr_build_list(int i, double *lval, int *lcol, double *ltau)
+    {
+        const int lane = bc.lane;
+        const double *row = C + (size_t)i * n;
+        double a0 = pos_inf(), a1 = pos_inf(), a2 = pos_inf(), r0 = 0.0, r1 = 0.0;
+        int j0 = -1, j1 = -1;
+        bool nan0 = false;
+        constexpr int U = 4;
+        for (int jb = 0; jb < n; jb += U * kWave) {
+            double c[U], vv[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const int j = jb + q * kWave + lane;
+                c[q] = row[(j < n) ? j : n - 1];
+                vv[q] = v[(j < n) ? j : n - 1];
+            }
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const int j = jb + q * kWave + lane;
+                const double xq = c[q] - vv[q];
+                if (j == 0) nan0 = !(xq == xq);
+                if (j < n && xq < a2) {  // strict: among equal values of a class the lower column stays ahead
+                    if (xq < a1) {
+                        a2 = a1;
+                        if (xq < a0) {
+                            a1 = a0, r1 = r0, j1 = j0;
+                            a0 = xq, r0 = c[q], j0 = j;
+                        } else {
+                            a1 = xq, r1 = c[q], j1 = j;
+                        }
+                    } else {
+                        a2 = xq;
+                    }
+                }
+            }
+        }
+        double tau = wave_min(a2);
+        // a NaN in column 0 poisons the serial scan's running minimum (lapjv.cpp:87-104): such a row
+        // always takes the full scan, which reproduces that
+        if (__ballot(nan0)) tau = -pos_inf();
+        const size_t o = (size_t)i * kArrListLen + lane;
+        lcol[o] = j0;
+        lval[o] = r0;
+        lcol[o + kWave] = j1;
+        lval[o + kWave] = r1;
+        if (lane == 0) ltau[i] = tau;
+    }
+
+    // lapjv.cpp:84-147: one iteration of the augmenting row reduction by the whole workgroup (two-minimum
+    // scan of the row, dual update, reassignment) for the sweep with candidate lists -- the body of
+    // cold_arr_sweep_plain()'s loop.  Returns false on the iteration guard.
+    __device__ __forceinline__ bool arr_scan_row(unsigned &current, unsigned &rr, int &new_free, int &fwd,
+                                                 int &free_i_out)
+    {
+        const int b0 = base();
+        const unsigned un = (unsigned)n;
+        rr++;
+        const int free_i = (fwd >= 0) ? fwd : fr[current];
+        fwd = -1;
+        current++;
+        const double *row = C + (size_t)free_i * n;
+        double v1, v2;
+        int j1, j2;
+        // Normal regime (column 0 not above the sentinel): the two smallest (value, index)
+        // pairs among column 0, the columns with c < LARGE and the LARGE sentinel (which
+        // only loses a tie to column 0).  c0 is owned by thread 0 and broadcast with the
+        // reduction, so no thread reads a v[] entry it does not own before the barrier.
+        double cs[CH];
+        double c0 = 0.0;
+        Arr2 t = arr2_empty();
+        if (bc.tid == 0) arr2_push(t, kLarge, kSentinelIdx, 0.0, -1);
+#pragma unroll
+        for (int r = 0; r < CH; ++r) cs[r] = row[(b0 + r < n) ? b0 + r : n - 1];
+#pragma unroll
+        for (int r = 0; r < CH; ++r) pin(cs[r]);
+#pragma unroll
+        for (int r = 0; r < CH; ++r) {
+            const int j = b0 + r;
+            const int jc = (j < n) ? j : n - 1;
+            const double vj = v[jc];
+            const int yj = y[jc];  // owner-only reads: v[j], y[j] are written by their owner
+            const double cv = cs[r] - vj;
+            cs[r] = (j < n) ? cv : pos_inf();
+            if (j == 0) c0 = cv;
+            if (j < n && (j == 0 || cv < kLarge)) arr2_push(t, cv, j, vj, yj);
+        }
+        t = bc.arr2(t, &c0);
+        int i0, i0_second;
+        double vj1;
+        if (c0 <= kLarge) {
+            // everything the serial code reads next came along as payload: no second barrier
+            v1 = t.a1;
+            j1 = t.i1;
+            v2 = t.a2;
+            j2 = (t.i2 == kSentinelIdx) ? -1 : t.i2;
+            i0 = t.y1;
+            i0_second = (j2 >= 0) ? t.y2 : -1;
+            vj1 = t.vj1;
+        } else {
+            // column 0 starts above the sentinel: nothing is accepted before the first
+            // column with c < LARGE; from there on it is a plain two-minimum scan that
+            // still holds (c0, 0) as a candidate.  Rare: keep the simple two-barrier form.
+            int js = kEmptyIdx;
+#pragma unroll
+            for (int r = 0; r < CH; ++r) {
+                const int j = b0 + r;
+                if (j < n && j >= 1 && cs[r] < kLarge && j < js) js = j;
+            }
+            js = bc.min_i32(js);
+            if (js == kEmptyIdx) {
+                v1 = c0;
+                j1 = 0;
+                v2 = kLarge;
+                j2 = -1;
+            } else {
+                Top2 t2 = top2_empty();
+#pragma unroll
+                for (int r = 0; r < CH; ++r) {
+                    const int j = b0 + r;
+                    if (j < n && (j == 0 || j >= js) && cs[r] == cs[r]) top2_push(t2, cs[r], j);
+                }
+                t2 = bc.top2(t2);
+                v1 = t2.a1;
+                j1 = t2.i1;
+                v2 = t2.a2;
+                j2 = t2.i2;
+            }
+            // uniform reads of entries owned by other threads, then a barrier, then the
+            // owners' writes: nobody may see this iteration's update while still reading.
+            i0 = y[j1];
+            i0_second = (j2 >= 0) ? y[j2] : -1;
+            vj1 = v[j1];
+            __syncthreads();
+        }
+        arr_iters++;
+        const double v1_new = vj1 - (v2 - v1);
+        const bool lowers = v1_new < vj1;
+        if (rr < current * un) {
+            if (lowers) {
+                if (j1 >= b0 && j1 < b0 + CH) v[j1] = v1_new;
+            } else if (i0 >= 0 && j2 >= 0) {
+                j1 = j2;
+                i0 = i0_second;
+            }
+            if (i0 >= 0) {
+                if (lowers) {
+                    --current;
+                    fwd = i0;
+                    if (bc.tid == 0) fr[current] = i0;
+                } else {
+                    if (bc.tid == 0) fr[new_free] = i0;
+                    ++new_free;
+                }
+            }
+        } else if (i0 >= 0) {
+            if (bc.tid == 0) fr[new_free] = i0;
+            ++new_free;
+        }
+        if (bc.tid == 0) x[free_i] = j1;
+        if (j1 >= b0 && j1 < b0 + CH) y[j1] = free_i;
+        if (arr_iters > (1 << 26)) {
+            err = 4;
+            return false;
+        }
+        free_i_out = free_i;
+        return true;
+    }
+
+    // lapjv.cpp:76-149.  One augmenting-row-reduction sweep over fr[0..n_free): every iteration scans its row.
+    // (Kept word for word as in round 2, beside arr_scan_row() below: the seeded kernel's register allocation
+    // follows the text of this function -- built from the shared helper it cost K4 3 %.)
+    __device__ __forceinline__ int cold_arr_sweep_plain(int n_free)
     {
         const int b0 = base();
         unsigned current = 0, rr = 0;
@@ -1437,13 +1635,206 @@ struct Solver {
         return new_free;
     }
 
+    // The same sweep with the candidate lists in front of the row scans.
+    template <bool LISTS>
+    __device__ __forceinline__ int cold_arr_sweep(int n_free, double *lval, int *lcol, double *ltau)
+    {
+        unsigned current = 0, rr = 0;
+        int new_free = 0;
+        int fwd = -1;
+        const unsigned un = (unsigned)n;
+        bool lists = LISTS && lval != nullptr;
+        int n_fast = 0, n_slow = 0;
+        ArrState *as = reinterpret_cast<ArrState *>(&ctrl->rec[0][0]);
+        if (LISTS && lists) {
+            // every row's list at the v the sweep starts from (the second sweep finds them in place:
+            // v has only decreased since)
+            if (ltau[0] != ltau[0]) {  // (uniform; NaN marks "not built yet", set by the caller)
+                __syncthreads();
+                for (int i = bc.wave; i < n; i += bc.nwaves) arr_build_list(i, lval, lcol, ltau);
+                fence_if_global();
+                __threadfence_block();
+                __syncthreads();
+            }
+        }
+        while (true) {
+            if (LISTS && lists) {
+                if (bc.wave == 0) {
+                    const int lane = bc.lane;
+                    int bad = 0;
+                    // list of the row the previous iteration expected to displace, requested as soon as
+                    // that row was known (before the second minimum and the updates)
+                    int cand = -1, pca = -1, pcb = -1;
+                    double pra = 0.0, prb = 0.0, ptau = 0.0;
+                    while (current < (unsigned)n_free) {
+                        const int free_i = (fwd >= 0) ? fwd : fr[current];
+                        if (free_i != cand) {
+                            const size_t o = (size_t)free_i * kArrListLen + lane;
+                            pca = lcol[o], pcb = lcol[o + kWave];
+                            pra = lval[o], prb = lval[o + kWave];
+                            ptau = ltau[free_i];
+                        }
+                        const int ca = pca, cb = pcb;
+                        const double ra = pra, rb = prb;
+                        const double tau = ptau;
+                        cand = -1;
+                        const int qa = (ca >= 0) ? ca : 0, qb = (cb >= 0) ? cb : 0;
+                        const double va = v[qa], vb = v[qb];
+                        const int ya_ = y[qa], yb_ = y[qb];
+                        const double xa = (ca >= 0) ? ra - va : pos_inf();
+                        const double xb = (cb >= 0) ? rb - vb : pos_inf();
+                        // this lane's two candidates in (value, column) order; NaN sorts last
+                        const bool swap = pair_less(xb, cb, xa, ca) || (!(xa == xa) && xb == xb);
+                        const double l1 = swap ? xb : xa, l2 = swap ? xa : xb;
+                        const int i1 = swap ? cb : ca, i2 = swap ? ca : cb;
+                        const double w1 = swap ? vb : va;
+                        const int y1 = swap ? yb_ : ya_, y2 = swap ? ya_ : yb_;
+                        const double k1 = (l1 == l1) ? l1 : pos_inf(), k2 = (l2 == l2) ? l2 : pos_inf();
+                        // smallest (value, column) pair: the value by a DPP reduction; the column needs a
+                        // second reduction only when several lanes hold that value
+                        const double m1 = wave_min(k1);
+                        unsigned long long b1 = __ballot(k1 == m1 && i1 >= 0);
+                        int g1 = 0x7fffffff;
+                        if (__popcll(b1) == 1) {
+                            g1 = __builtin_amdgcn_readlane(i1, __builtin_ctzll(b1));
+                        } else if (b1) {
+                            g1 = wave_min_i32((k1 == m1 && i1 >= 0) ? i1 : 0x7fffffff);
+                            b1 = __ballot(k1 == m1 && i1 == g1);
+                        }
+                        const bool win = (k1 == m1) && (i1 == g1);
+                        if (b1) {
+                            const int i0s = __builtin_amdgcn_readlane(y1, __builtin_ctzll(b1));
+                            if ((unsigned)i0s < un) {
+                                cand = i0s;
+                                const size_t o = (size_t)i0s * kArrListLen + lane;
+                                pca = lcol[o], pcb = lcol[o + kWave];
+                                pra = lval[o], prb = lval[o + kWave];
+                                ptau = ltau[i0s];
+                            }
+                        }
+                        const double s2 = win ? k2 : k1;
+                        const int si = win ? i2 : i1, sy = win ? y2 : y1;
+                        const double m2 = wave_min(s2);
+                        unsigned long long b2 = __ballot(s2 == m2 && si >= 0);
+                        int g2 = 0x7fffffff;
+                        if (__popcll(b2) == 1) {
+                            g2 = __builtin_amdgcn_readlane(si, __builtin_ctzll(b2));
+                        } else if (b2) {
+                            g2 = wave_min_i32((s2 == m2 && si >= 0) ? si : 0x7fffffff);
+                            b2 = __ballot(s2 == m2 && si == g2);
+                        }
+                        const bool ok = (m2 < tau) && (m2 < kLarge) && (m1 > -kLarge) && g1 != 0x7fffffff && g2 != 0x7fffffff;
+                        if (!ok) break;  // (uniform) this row takes the full scan; nothing was changed
+                        const int ln1 = __builtin_ctzll(b1), ln2 = __builtin_ctzll(b2);
+                        const double vj1 = readlane_f64(w1, ln1);
+                        int i0 = __builtin_amdgcn_readlane(y1, ln1);
+                        const int i0_second = __builtin_amdgcn_readlane(sy, ln2);
+                        int j1 = g1;
+                        const int j2 = g2;
+                        rr++;
+                        current++;
+                        fwd = -1;
+                        arr_iters++;
+                        n_fast++;
+                        const double v1_new = vj1 - (m2 - m1);
+                        const bool lowers = v1_new < vj1;
+                        if (rr < current * un) {
+                            if (lowers) {
+                                if (lane == 0) v[j1] = v1_new;
+                            } else if (i0 >= 0) {
+                                j1 = j2;
+                                i0 = i0_second;
+                            }
+                            if (i0 >= 0) {
+                                if (lowers) {
+                                    --current;
+                                    fwd = i0;
+                                    if (lane == 0) fr[current] = i0;
+                                } else {
+                                    if (lane == 0) fr[new_free] = i0;
+                                    ++new_free;
+                                }
+                            }
+                        } else if (i0 >= 0) {
+                            if (lane == 0) fr[new_free] = i0;
+                            ++new_free;
+                        }
+                        if (lane == 0) {
+                            x[free_i] = j1;
+                            y[j1] = free_i;
+                        }
+                        fence_if_global();  // (state in global memory: the next iteration's lanes read these)
+                        if (arr_iters > (1 << 26)) {
+                            bad = 4;
+                            break;
+                        }
+                    }
+                    if (lane == 0) {
+                        as->arr_current = current;
+                        as->arr_rr = rr;
+                        as->arr_new_free = new_free;
+                        as->arr_fwd = fwd;
+                        as->arr_iters = arr_iters;
+                        as->arr_fast = n_fast;
+                        as->arr_err = bad;
+                    }
+                }
+                fence_if_global();
+                __syncthreads();
+                current = as->arr_current;
+                rr = as->arr_rr;
+                new_free = as->arr_new_free;
+                fwd = as->arr_fwd;
+                arr_iters = as->arr_iters;
+                n_fast = as->arr_fast;
+                if (as->arr_err) {
+                    err = as->arr_err;
+                    break;
+                }
+            }
+            if (current >= (unsigned)n_free) break;
+            int free_i = 0;
+            if (!arr_scan_row(current, rr, new_free, fwd, free_i)) break;
+            if (LISTS && lists) {
+                // the owners' writes of this iteration, then the list of this row at today's v by wave 0
+                // (it is the one that reads it next); a family whose lists keep going stale faster than
+                // they pay (more full scans than list iterations after the first 256) stops using them
+                ++n_slow;
+                fence_if_global();
+                __syncthreads();
+                if (n_slow >= 256 && n_fast < n_slow) {
+                    lists = false;
+                } else if (bc.wave == 0) {
+                    arr_build_list(free_i, lval, lcol, ltau);
+                    fence_if_global();
+                }
+            }
+        }
+        __syncthreads();
+        if (bc.tid == 0) ctrl->first_fire += n_fast;  // (stats; the field is the micro-ARR's, which a cold solve never runs)
+        return new_free;
+    }
+
     // lapjv.cpp:323-346
     // Column reduction + the two ARR sweeps; returns the rows still free (the caller runs the
     // shortest-path phase, which is shared with the seeded branch -- one call site, one copy).
-    __device__ __forceinline__ int cold_prepare()
+    template <bool LISTS>
+    __device__ __forceinline__ int cold_prepare(double *lval, int *lcol, double *ltau)
     {
         int nf = cold_column_reduction();
-        for (int sweep = 0; nf > 0 && sweep < 2 && !err; ++sweep) nf = cold_arr_sweep(nf);
+        if (LISTS && bc.tid == 0) ctrl->first_fire = 0;  // (counts the list iterations: stats slot 27)
+        if (LISTS && lval && nf > 0) {
+            if (bc.tid == 0) ltau[0] = __longlong_as_double(0x7ff8000000000000LL);  // "lists not built yet"
+            fence_if_global();
+            __threadfence_block();
+            __syncthreads();
+        }
+        for (int sweep = 0; nf > 0 && sweep < 2 && !err; ++sweep) {
+            if constexpr (LISTS)
+                nf = cold_arr_sweep<true>(nf, lval, lcol, ltau);
+            else
+                nf = cold_arr_sweep_plain(nf);
+        }
         return nf;
     }
 
@@ -1539,7 +1930,21 @@ struct Solver {
 
 // TB = compile-time bound on the workgroup size: 1024-thread workgroups cap a thread at 128 VGPRs,
 // the 256-thread variant (one wave per SIMD) gets the whole register file.
-template <int CH, int LDSL, int TB>
+// LISTS = true: the PREPARATION of a cold solve with per-row candidate lists in the augmenting row reduction
+// (cold_arr_sweep<true>) and nothing else: it is only ever launched as phase 1 (column reduction + row
+// reduction, state handed over through the global arrays) by the cold entry points (lap.lapjv), and the
+// shortest-path phase follows in the plain instantiation (phase 2).  Three arrangements were measured first:
+//  * list code compiled into the one kernel: its register pressure is paid by the shortest-path loops of
+//    EVERY instance (SGPR spills 170 -> 213; K3 76.5 -> 79 ms, K4 288 -> 310 ms);
+//  * a seeded-only kernel with the full kernel launched behind it for the quality-gate fallbacks: those then
+//    run AFTER the seeded instances of the batch instead of beside them (K3 76.6 -> 81.7 ms);
+//  * this instantiation running the shortest-path phase itself: integer-cost instances (int100, n = 1536 /
+//    2048, 512 threads x 4 columns) came out of a CORRECT row reduction (same state handed to the cooperative
+//    kernel: exact, six runs of six) and then failed in the shortest-path loops, differently from run to run
+//    (ret -106 / -103 / wrong x) -- the same source that is exact in the plain instantiation.  Not explained
+//    (the instantiation spills 87 VGPRs there against 30); avoided by not compiling those loops in here.
+// The seeded launches keep the plain row scans for their fallbacks: the code, and the timing, of round 2.
+template <int CH, int LDSL, int TB, bool LISTS>
 __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1729,7 +2134,7 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
         const int *hand = p.hand + (size_t)b * kHandInts;
         if (hand[3] == 0 || hand[2] != 0 || hand[4] != 0 || hand[1] >= hand[0]) return;  // nothing pending (uniform)
     }
-    if (p.phase == 2 || p.phase == 3) {
+    if (!LISTS && (p.phase == 2 || p.phase == 3)) {
         // ---- resume behind the cooperative kernel: x, y, v and the free rows come back from the
         // global state arrays, the rows hand[1] .. hand[0] are still to be augmented
         const size_t o = (size_t)b * n;
@@ -1814,10 +2219,17 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
     bool run_paths = false;
     if (p.phase >= 2) {
     } else if (cold) {
-        nf = s.cold_prepare();
+        if constexpr (LISTS) {
+            const size_t lo_ = (size_t)b * n;
+            nf = s.template cold_prepare<true>(p.arr_lval ? p.arr_lval + lo_ * kArrListEntries : nullptr,
+                                               p.arr_lval ? p.arr_lcol + lo_ * kArrListEntries : nullptr,
+                                               p.arr_lval ? p.arr_ltau + lo_ : nullptr);
+        } else {
+            nf = s.template cold_prepare<false>(nullptr, nullptr, nullptr);
+        }
         free_after_greedy = nf;
         run_paths = nf > 0;
-    } else {
+    } else if constexpr (!LISTS) {
         if (s.bc.wave == 0) s.greedy_wave0(p.tight_bits + (size_t)b * n * W, p.tight_cnt + (size_t)b * n);
         __syncthreads();
         nf = s.ctrl->nfree;
@@ -1860,12 +2272,18 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
             hand[11] = (int)(s.colred_elems & 0xffffffffLL);
             hand[12] = (int)(s.colred_elems >> 32);
             hand[13] = e1;
+            hand[14] = LISTS ? s.ctrl->first_fire : 0;  // row-reduction iterations answered from the candidate lists
+            {  // this launch's duration, 10 ns ticks (phase 2 adds it to stats slot 13)
+                const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - t_start;
+                hand[15] = (dt < 0x7fffffffull) ? (int)dt : 0x7fffffff;
+            }
             if (p.cstats) {
                 for (int q = 0; q < kCoopStats; ++q) p.cstats[(size_t)b * kCoopStats + q] = 0;
             }
         }
         return;
     }
+    if constexpr (LISTS) return;  // (phase 1 only: everything below belongs to the plain instantiation)
     if (p.phase == 0 && run_paths && !s.err) s.augment_all(0, nf);
     __syncthreads();
     const int err = s.err | s.ctrl->err;
@@ -1905,12 +2323,14 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
             st[12] = err;
             const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
             st[13] = (long long)(t_end - t_start);     // whole kernel, 10 ns ticks
+            if (p.phase == 2) st[13] += p.hand[(size_t)b * kHandInts + 15];  // + the preparation launch
             st[14] = (long long)(t_serial - t_start);  // greedy + micro-ARR part (SSP branch)
             // paths the cooperative kernel completed | why it stopped early << 32 (-1: not used)
-            st[15] = (p.phase == 2) ? ((long long)p.hand[(size_t)b * kHandInts + 1] |
+            st[15] = (p.phase == 2 && p.mail) ? ((long long)p.hand[(size_t)b * kHandInts + 1] |
                                        ((long long)p.hand[(size_t)b * kHandInts + 3] << 32))
                                     : -1;
             for (int q = 16; q < kStatsPerInstance; ++q) st[q] = 0;
+            if (p.phase == 2) st[27] = p.hand[(size_t)b * kHandInts + 14];  // row-reduction iterations answered from the candidate lists
             if (p.phase == 2 && p.cstats) {
                 for (int q = 0; q < 11; ++q) st[16 + q] = p.cstats[(size_t)b * kCoopStats + 5 + q];  // exchange rounds; stamps
             }
@@ -1921,10 +2341,10 @@ __global__ void __launch_bounds__(TB) jv_instance_kernel(SolverParams p)
     }
 }
 
-template <int CH, int LDSL, int TB>
+template <int CH, int LDSL, int TB, bool LISTS>
 hipError_t launch_one(const SolverParams &p, int threads, size_t lds_bytes, hipStream_t stream)
 {
-    auto kern = jv_instance_kernel<CH, LDSL, TB>;
+    auto kern = jv_instance_kernel<CH, LDSL, TB, LISTS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
@@ -1934,6 +2354,15 @@ hipError_t launch_one(const SolverParams &p, int threads, size_t lds_bytes, hipS
 }
 
 }  // namespace
+
+bool arr_lists_enabled(int n)
+{
+    static const int on = [] {
+        const char *e = getenv("LAPWARM_ARR_LISTS");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return on && n >= 512;
+}
 
 // LDS levels: 2 = position-owned search, every array in LDS; 1 = x and the free-row list in global
 // memory; 0 = all global; 8 = all global + head rows staged in LDS row slots.
@@ -2025,6 +2454,13 @@ bool solver_uses_helpers(int n)
 
 static hipError_t launch_phase(const SolverParams &p_in, int threads_hint, hipStream_t stream);
 
+// Does this launch use the instantiation with the candidate-list row reduction?  (Cold solves whose
+// caller provided the list workspace; their phase 0 or, with the cooperative shortest-path phase, phase 1.)
+static bool phase_uses_lists(const SolverParams &p)
+{
+    return p.mode == kModeCold && p.phase == 1 && p.arr_lval && p.arr_lcol && p.arr_ltau && p.hand && p.g_x;
+}
+
 // The whole solve: one launch of jv_instance_kernel, or -- where the cooperative shortest-path phase
 // is enabled for this size (coop_ssp.hip) -- three: phase 1 (greedy / micro-ARR / cold preparation),
 // the cooperative kernel, phase 2 (whatever it left + the outputs).
@@ -2032,6 +2468,16 @@ hipError_t launch_solver(const SolverParams &p_in, int threads_hint, hipStream_t
 {
     if (!(coop_enabled(p_in.n) && p_in.hand && p_in.mail && p_in.cstats && p_in.g_x)) {
         SolverParams p = p_in;
+        p.phase = 1;
+        p.mail = nullptr;
+        p.mail_granules = 0;
+        if (phase_uses_lists(p)) {
+            // cold solve with candidate lists: preparation in its own instantiation, then the shortest paths
+            hipError_t e = launch_phase(p, threads_hint, stream);
+            if (e != hipSuccess) return e;
+            p.phase = 2;
+            return launch_phase(p, threads_hint, stream);
+        }
         p.phase = 0;
         return launch_phase(p, threads_hint, stream);
     }
@@ -2115,27 +2561,37 @@ static hipError_t launch_phase(const SolverParams &p_in, int threads_hint, hipSt
     if (threads_hint <= 0 && p.mode == kModeSeeded && large_row_geometry(p.n, &threads, &ch)) {
         if (!p.g_x) return hipErrorInvalidValue;
         const size_t lds8 = solver_lds_bytes(p.n, ch, 8);
-        return launch_one<16, 8, 512>(p, threads, lds8, stream);
+        return launch_one<16, 8, 512, false>(p, threads, lds8, stream);
     }
     const int level = solver_lds_level(p.n, ch);
     if (level < 2 && !p.g_x) return hipErrorInvalidValue;
     const size_t lds = solver_lds_bytes(p.n, ch, level);
-#define LAPWARM_CASE(CHV)                                                               \
-    case CHV:                                                                           \
-        if (threads <= 256) {                                                           \
-            if (level == 2) return launch_one<CHV, 2, 256>(p, threads, lds, stream);    \
-            if (level == 1) return launch_one<CHV, 1, 256>(p, threads, lds, stream);    \
-            return launch_one<CHV, 0, 256>(p, threads, lds, stream);                    \
-        }                                                                               \
-        if (level == 2) return launch_one<CHV, 2, 1024>(p, threads, lds, stream);       \
-        if (level == 1) return launch_one<CHV, 1, 1024>(p, threads, lds, stream);       \
-        return launch_one<CHV, 0, 1024>(p, threads, lds, stream);
-    switch (ch) {
-        LAPWARM_CASE(1)
-        LAPWARM_CASE(2)
-        LAPWARM_CASE(4)
-        LAPWARM_CASE(8)
-        LAPWARM_CASE(16)
+#define LAPWARM_CASE(CHV, LISTV)                                                              \
+    case CHV:                                                                                  \
+        if (threads <= 256) {                                                                  \
+            if (level == 2) return launch_one<CHV, 2, 256, LISTV>(p, threads, lds, stream);    \
+            if (level == 1) return launch_one<CHV, 1, 256, LISTV>(p, threads, lds, stream);    \
+            return launch_one<CHV, 0, 256, LISTV>(p, threads, lds, stream);                    \
+        }                                                                                      \
+        if (level == 2) return launch_one<CHV, 2, 1024, LISTV>(p, threads, lds, stream);       \
+        if (level == 1) return launch_one<CHV, 1, 1024, LISTV>(p, threads, lds, stream);       \
+        return launch_one<CHV, 0, 1024, LISTV>(p, threads, lds, stream);
+    if (!phase_uses_lists(p)) {
+        switch (ch) {
+            LAPWARM_CASE(1, false)
+            LAPWARM_CASE(2, false)
+            LAPWARM_CASE(4, false)
+            LAPWARM_CASE(8, false)
+            LAPWARM_CASE(16, false)
+        }
+    } else {
+        switch (ch) {
+            LAPWARM_CASE(1, true)
+            LAPWARM_CASE(2, true)
+            LAPWARM_CASE(4, true)
+            LAPWARM_CASE(8, true)
+            LAPWARM_CASE(16, true)
+        }
     }
 #undef LAPWARM_CASE
     return hipErrorInvalidValue;

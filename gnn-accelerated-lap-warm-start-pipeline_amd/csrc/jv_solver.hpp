@@ -55,13 +55,19 @@ struct SolverParams {
     long long *cstats;         // [batch][kCoopStats] path counters of the cooperative kernel
     unsigned long long *mail;  // [batch][coop_mail_granules(n)] zeroed by phase 1
     int mail_granules;
+    // candidate lists of the augmenting row reduction (cold solves, lapwarm_lapjv_*_batched):
+    // [batch][n][kArrListEntries] raw costs / columns, [batch][n] thresholds; null = plain row scans
+    // (last: a member in the middle moved the kernel arguments behind it and cost the seeded kernel 12 SGPR spills)
+    double *arr_lval, *arr_ltau;
+    int *arr_lcol;
 };
+constexpr int kArrListEntries = 128;
 constexpr int kRingSlots = 64;
 constexpr int kRingInts = 2 + kRingSlots;
 
 // hand[]: 0 free rows, 1 paths done by the cooperative kernel (resume index), 2 its error code,
 // 3 why it stopped early, 4 error seen by a member other than the leader, 5.. what phase 1 knows
-// and phase 2 reports (branch, tight edges, free rows after greedy, micro-ARR firings, transfer
+// and phase 2 reports (14: row-reduction iterations answered from candidate lists, 15: duration of the phase-1 launch) (branch, tight edges, free rows after greedy, micro-ARR firings, transfer
 // rows, ARR iterations, column-reduction elements lo/hi, phase-1 error)
 constexpr int kHandInts = 16;
 constexpr int kCoopStats = 16;
@@ -87,6 +93,9 @@ hipError_t launch_coop(const CoopParams &p, hipStream_t stream);
 size_t solver_lds_bytes(int n, int ch, int level);
 int solver_lds_level(int n, int ch);
 bool solver_needs_global_state(int n);
+// candidate lists for the augmenting row reduction: from the size where a row is a few times its list
+// (LAPWARM_ARR_LISTS=0 turns them off: every iteration then scans its whole row)
+bool arr_lists_enabled(int n);
 void solver_geometry(int n, int threads_hint, int *threads, int *ch);
 hipError_t launch_solver(const SolverParams &p, int threads_hint, hipStream_t stream);
 bool solver_uses_helpers(int n);  // seeded mode with a ring: one helper workgroup per instance

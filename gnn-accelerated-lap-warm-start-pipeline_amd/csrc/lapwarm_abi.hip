@@ -55,10 +55,12 @@ struct SeededWs {
     int *hand;
     long long *cstats;
     unsigned long long *mail;
+    double *arr_lval, *arr_ltau;
+    int *arr_lcol;
     size_t bytes;
 };
 
-SeededWs carve_seeded(void *ws, int batch, int n)
+SeededWs carve_seeded(void *ws, int batch, int n, bool with_lists = false)
 {
     SeededWs s;
     Carver c{reinterpret_cast<unsigned char *>(ws), 0};
@@ -73,10 +75,12 @@ SeededWs carve_seeded(void *ws, int batch, int n)
     s.tight_bits = c.take<uint32_t>(bn * W);
     s.pf_ring = c.take<int>((size_t)batch * kRingInts);
     const bool coop = coop_enabled(n);
-    s.hand = coop ? c.take<int>((size_t)batch * kHandInts) : nullptr;
-    s.cstats = coop ? c.take<long long>((size_t)batch * kCoopStats) : nullptr;
+    // (a cold solve with candidate lists hands its preparation over to a second launch the same way)
+    const bool two_phase = coop || (with_lists && arr_lists_enabled(n));
+    s.hand = two_phase ? c.take<int>((size_t)batch * kHandInts) : nullptr;
+    s.cstats = two_phase ? c.take<long long>((size_t)batch * kCoopStats) : nullptr;
     s.mail = coop ? c.take<unsigned long long>((size_t)batch * coop_mail_granules(n)) : nullptr;
-    if (solver_needs_global_state(n) || coop) {
+    if (solver_needs_global_state(n) || two_phase) {
         s.g_dist = c.take<double>(bn);
         s.g_v = c.take<double>(bn);
         s.g_order = c.take<int>(bn);
@@ -89,6 +93,15 @@ SeededWs carve_seeded(void *ws, int batch, int n)
     } else {
         s.g_dist = s.g_v = nullptr;
         s.g_order = s.g_pred = s.g_y = s.g_x = s.g_fr = s.g_evl = s.g_tmpcol = nullptr;
+    }
+    // candidate lists of the augmenting row reduction (jv_solver.hip, cold_arr_sweep): 1,544 bytes per row
+    if (with_lists && arr_lists_enabled(n)) {
+        s.arr_lval = c.take<double>(bn * kArrListEntries);
+        s.arr_lcol = c.take<int>(bn * kArrListEntries);
+        s.arr_ltau = c.take<double>(bn);
+    } else {
+        s.arr_lval = s.arr_ltau = nullptr;
+        s.arr_lcol = nullptr;
     }
     s.bytes = c.off;
     return s;
@@ -204,6 +217,12 @@ size_t lapwarm_seeded_workspace_bytes(int batch, int n)
     return carve_seeded(nullptr, batch, n).bytes;
 }
 
+size_t lapwarm_lapjv_workspace_bytes(int batch, int n)
+{
+    if (check_dims(batch, n)) return 0;
+    return carve_seeded(nullptr, batch, n, true).bytes;
+}
+
 size_t lapwarm_sweep_workspace_bytes(int batch, int n)
 {
     if (check_dims(batch, n)) return 0;
@@ -307,7 +326,10 @@ static int lapjv_batched_impl(const double *C, int batch, int n, int *x, int *y,
 {
     if (int rc = check_dims(batch, n)) return rc;
     hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-    SeededWs w = carve_seeded(workspace, batch, n);
+    // a workspace of lapwarm_lapjv_workspace_bytes() carries the candidate lists of the row reduction;
+    // the smaller lapwarm_seeded_workspace_bytes() is still accepted (plain row scans then)
+    SeededWs w = carve_seeded(workspace, batch, n, true);
+    if (workspace_bytes < w.bytes) w = carve_seeded(workspace, batch, n, false);
     if (workspace_bytes < w.bytes) {
         snprintf(g_err, sizeof(g_err), "workspace too small: %zu < %zu", workspace_bytes, w.bytes);
         return -1;
@@ -333,6 +355,9 @@ static int lapjv_batched_impl(const double *C, int batch, int n, int *x, int *y,
     sp.g_fr = w.g_fr;
     sp.g_evl = w.g_evl;
     sp.g_tmpcol = w.g_tmpcol;
+    sp.arr_lval = w.arr_lval;
+    sp.arr_lcol = w.arr_lcol;
+    sp.arr_ltau = w.arr_ltau;
     sp.hand = w.hand;
     sp.cstats = w.cstats;
     sp.mail = w.mail;
@@ -453,7 +478,7 @@ int lapwarm_lapjv_dense(const double *C, int n, int *x, int *y)
     if (n <= 0) return -2;
     if (n > 16384) return -5;
     std::lock_guard<std::mutex> lock(g_arena.mu);
-    const size_t ws_bytes = lapwarm_seeded_workspace_bytes(1, n);
+    const size_t ws_bytes = lapwarm_lapjv_workspace_bytes(1, n);
     const size_t total = align_up(sizeof(double) * (size_t)n * n) + 2 * align_up(sizeof(int) * n) + 256 + ws_bytes;
     if (g_arena.reserve(total) != hipSuccess) return -1;
     Carver c{reinterpret_cast<unsigned char *>(g_arena.ptr), 0};
@@ -480,7 +505,7 @@ int lapwarm_warmstart_lapjv(const double *C, int n, const double *u, const doubl
     if (n > 16384) return -5;
     std::lock_guard<std::mutex> lock(g_arena.mu);
     const size_t ws_sweep = lapwarm_sweep_workspace_bytes(1, n);
-    const size_t ws_solve = lapwarm_seeded_workspace_bytes(1, n);
+    const size_t ws_solve = lapwarm_lapjv_workspace_bytes(1, n);
     const size_t mat = align_up(sizeof(double) * (size_t)n * n);
     const size_t total = 2 * mat + 3 * align_up(sizeof(double) * n) + 2 * align_up(sizeof(int) * n) + 512 +
                          ws_sweep + ws_solve;

@@ -69,15 +69,16 @@ class WarmStartPipeline:
         self.threads_hint = int(threads_hint)
         self._ws = {}
 
-    def _workspace(self, B, n):
-        key = (B, n)
+    def _workspace(self, B, n, cold=False):
+        # (cold solves carry the candidate lists of the row reduction: a larger block, cached separately)
+        key = (B, n, cold)
         if key not in self._ws:
             if len(self._ws) >= 4:  # a handful of shapes at most: drop the oldest
                 # kernels of an earlier call may still be running on it (any stream), and a captured
                 # graph may hold its address: wait for the device before the block can be handed out again
                 torch.cuda.synchronize(self.device)
                 self._ws.pop(next(iter(self._ws)))
-            nbytes = self.lib.lapwarm_seeded_workspace_bytes(B, n)
+            nbytes = (self.lib.lapwarm_lapjv_workspace_bytes if cold else self.lib.lapwarm_seeded_workspace_bytes)(B, n)
             self._ws[key] = (torch.empty((nbytes,), dtype=torch.uint8, device=self.device), nbytes)
         ws = self._ws[key]
         # the caching allocator must not recycle the block while the stream that uses it now still runs
@@ -123,7 +124,7 @@ class WarmStartPipeline:
         y = torch.empty((B, n), dtype=torch.int32, device=C.device)
         ret = torch.empty((B,), dtype=torch.int32, device=C.device)
         stats = torch.zeros((B, 32), dtype=torch.int64, device=C.device) if want_stats else None
-        ws, nbytes = self._workspace(B, n)
+        ws, nbytes = self._workspace(B, n, cold=True)
         stream = torch.cuda.current_stream(C.device).cuda_stream
         rc = self.lib.lapwarm_lapjv_batched(C.data_ptr(), B, n, x.data_ptr(), y.data_ptr(), ret.data_ptr(),
                                             stats.data_ptr() if want_stats else None, ws.data_ptr(), nbytes,
@@ -142,7 +143,7 @@ class WarmStartPipeline:
         u = torch.empty((B, n), dtype=torch.float64, device=C.device)
         v = torch.empty((B, n), dtype=torch.float64, device=C.device)
         ret = torch.empty((B,), dtype=torch.int32, device=C.device)
-        ws, nbytes = self._workspace(B, n)
+        ws, nbytes = self._workspace(B, n, cold=True)
         stream = torch.cuda.current_stream(C.device).cuda_stream
         rc = self.lib.lapwarm_lapjv_duals_batched(C.data_ptr(), B, n, x.data_ptr(), y.data_ptr(), u.data_ptr(),
                                                   v.data_ptr(), ret.data_ptr(), None, ws.data_ptr(), nbytes,

@@ -32,6 +32,7 @@ SIGNATURES = {
     "lapwarm_reduce_costs": (ct.c_int, [c_dp, ct.c_int, c_dp, c_dp, ct.c_int, c_dp, c_dp]),
     "lapwarm_warmstart_lapjv": (ct.c_int, [c_dp, ct.c_int, c_dp, c_dp, ct.c_int, c_ip, c_ip]),
     "lapwarm_seeded_workspace_bytes": (ct.c_size_t, [ct.c_int, ct.c_int]),
+    "lapwarm_lapjv_workspace_bytes": (ct.c_size_t, [ct.c_int, ct.c_int]),
     "lapwarm_seeded_batched": (ct.c_int, [c_vp, ct.c_int, ct.c_int, c_vp, c_vp, ct.c_double, c_vp, c_vp,
                                           c_vp, c_vp, c_vp, ct.c_size_t, ct.c_int, c_vp]),
     "lapwarm_lapjv_batched": (ct.c_int, [c_vp, ct.c_int, ct.c_int, c_vp, c_vp, c_vp, c_vp, c_vp,

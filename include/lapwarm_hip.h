@@ -78,6 +78,10 @@ int lapwarm_warmstart_lapjv(const double *C, int n, const double *u, const doubl
  * 14 greedy+micro-ARR time (10 ns ticks); 16..31 cycle stamps, only in -DLAPWARM_STAMPS builds. */
 
 size_t lapwarm_seeded_workspace_bytes(int batch, int n);
+/* Workspace of the cold entry points below: the seeded workspace plus, from n = 512, the candidate lists
+ * of the augmenting row reduction (1,544 bytes per row).  A workspace of only
+ * lapwarm_seeded_workspace_bytes() is accepted too; every row-reduction iteration then scans its row. */
+size_t lapwarm_lapjv_workspace_bytes(int batch, int n);
 
 /* Batched lapjv_seeded over C[batch][n][n]; u_seed, v_seed [batch][n]; x, y [batch][n] int64;
  * ret [batch] int; stats [batch][32] int64 or NULL.  `threads_hint` = workgroup size of the
@@ -87,7 +91,7 @@ int lapwarm_seeded_batched(const double *C, int batch, int n, const double *u_se
                            long long *stats, void *workspace, size_t workspace_bytes,
                            int threads_hint, void *stream);
 
-/* Batched cold lapjv; x, y [batch][n] int32. Uses the same workspace size. */
+/* Batched cold lapjv; x, y [batch][n] int32.  Workspace: lapwarm_lapjv_workspace_bytes(). */
 int lapwarm_lapjv_batched(const double *C, int batch, int n, int *x, int *y, int *ret,
                           long long *stats, void *workspace, size_t workspace_bytes,
                           int threads_hint, void *stream);

@@ -793,3 +793,86 @@ def test_solver_wrappers_and_error_behaviour():
         lap.lapjv(np.zeros(3))
     ret = lap.lapjv(C[:3, :3][:, ::1][::1])  # non-contiguous view is copied (test_lapjv_non_contigous)
     assert len(ret) == 3
+
+
+# --------------------------------------------------------------------------- cold solve: candidate lists
+def test_cold_row_reduction_candidate_lists_families(torch_cuda):
+    """Cold `lapjv` at a size where the augmenting row reduction answers most iterations from per-row
+    candidate lists (jv_solver.hip, cold_arr_sweep; n >= 512): seven cost families, assignments
+    bit-exact and the ARR-iteration / path / relax-step counters equal to the oracle's (the lists change
+    how the two minima of a row are found, never which iterations happen).  Uniform, sparse and tie
+    costs must actually take the list path; low-rank and clustered ones go stale and take the full scan."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    from oracle import jv
+    from solvers.generators import mixed_batch
+    fams = ("uniform", "sparse", "metric", "clustered", "low_rank", "noisy_linear", "tie")
+    n = 704  # 11 x 64: the last class block of a list build is partial for n % 256 != 0
+    Cs, names = mixed_batch(len(fams), n, families=fams, seed=77)
+    pipe = WarmStartPipeline(OneGNN(21), "cuda:0")
+    x, y, ret, st = pipe.lapjv_batch(torch.from_numpy(Cs).cuda())
+    torch.cuda.synchronize()
+    st = st.cpu().numpy()
+    for b in range(len(fams)):
+        r, xo, yo, so = jv.dense_raw(Cs[b])
+        assert r == int(ret[b]) == 0, (names[b], st[b, 12])
+        assert np.array_equal(xo, x[b].cpu().numpy()) and np.array_equal(yo, y[b].cpu().numpy()), names[b]
+        for q, k in ((11, "arr_iters"), (4, "paths"), (5, "finds"), (6, "scan_steps"), (10, "transfer_rows")):
+            assert st[b, q] == so[k], (names[b], k, st[b, q], so[k])
+        if names[b] in ("uniform", "sparse", "tie"):
+            assert st[b, 27] > 0.9 * st[b, 11], (names[b], st[b, 27], st[b, 11])
+
+
+def test_quality_gate_fallback_beside_seeded_instances(torch_cuda):
+    """Seeds that fail the quality gate (lapjv_seeded.cpp:116; here all-zero seeds on positive costs: no
+    tight edge at all) take the cold branch inside the seeded kernel, in the same batch as instances
+    whose seeds pass -- at a size where the cold ENTRY points use the candidate lists, the seeded
+    launch must keep solving its fallbacks with plain row scans.  Both kinds bit-exact."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    from gnn.features import min_trick_device
+    from oracle import jv
+    B, n = 4, 640
+    Cs = np.stack([np.random.RandomState(3 + i).uniform(0.5, 1.5, (n, n)) for i in range(B)])
+    C = torch.from_numpy(Cs).cuda()
+    u = C.min(dim=2).values.contiguous()
+    v = min_trick_device(C, u)
+    u[1::2] = 0.0
+    v[1::2] = 0.0
+    pipe = WarmStartPipeline(OneGNN(21), "cuda:0")
+    x, y, ret, stats = pipe.seeded_batch(C, u, v)
+    torch.cuda.synchronize()
+    st = stats.cpu().numpy()
+    un, vn = u.cpu().numpy(), v.cpu().numpy()
+    branches = set()
+    for b in range(B):
+        r, xo, yo, so = jv.seeded_raw(Cs[b], un[b], vn[b])
+        assert r == int(ret[b]) == 0
+        assert np.array_equal(xo, x[b].cpu().numpy()) and np.array_equal(yo, y[b].cpu().numpy())
+        assert st[b, 0] == so["branch"] and st[b, 11] == so["arr_iters"] and st[b, 4] == so["paths"]
+        branches.add(int(so["branch"]))
+    assert len(branches) == 2, branches  # fallback and shortest-path instances side by side
+
+
+def test_cold_integer_costs_with_lists_repeatable(torch_cuda):
+    """Integer costs 1..100 at n = 1536 (512 threads x 4 columns per thread, a fifth of the row-reduction
+    iterations falling back to the full scan and rebuilding their list): the geometry that failed --
+    differently from run to run -- while the instantiation with the candidate lists also ran the shortest
+    paths.  Three solves of the same batch, each bit-exact."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    from oracle import jv
+    n, B = 1536, 2
+    Cs = np.stack([np.random.RandomState(5 + i).randint(1, 101, (n, n)).astype(np.float64) for i in range(B)])
+    C = torch.from_numpy(Cs).cuda()
+    pipe = WarmStartPipeline(OneGNN(21), "cuda:0")
+    ref = [jv.dense_raw(Cs[b]) for b in range(B)]
+    for rep in range(3):
+        x, y, ret, st = pipe.lapjv_batch(C)
+        torch.cuda.synchronize()
+        st = st.cpu().numpy()
+        for b in range(B):
+            r, xo, yo, so = ref[b]
+            assert r == int(ret[b]) == 0, (rep, b, int(ret[b]), st[b, 12])
+            assert np.array_equal(xo, x[b].cpu().numpy()) and np.array_equal(yo, y[b].cpu().numpy()), (rep, b)
+            assert st[b, 11] == so["arr_iters"] and st[b, 4] == so["paths"] and st[b, 27] > 0

@@ -53,6 +53,12 @@ def test_abi_library_loads_and_exports_every_declared_symbol():
     assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
     assert lib.lapwarm_seeded_workspace_bytes(32, 2048) > 32 * 2048 * 2048 // 8
     assert lib.lapwarm_seeded_workspace_bytes(1, 0) == 0
+    # cold solves: + the candidate lists of the row reduction from n = 512 (128 x 12 + 8 bytes per row) and the
+    # hand-over block of their two launches (solver state in global memory: 44 bytes per row)
+    assert lib.lapwarm_lapjv_workspace_bytes(3, 256) == lib.lapwarm_seeded_workspace_bytes(3, 256)
+    extra = lib.lapwarm_lapjv_workspace_bytes(3, 2048) - lib.lapwarm_seeded_workspace_bytes(3, 2048)
+    assert 3 * 2048 * 1544 <= extra <= 3 * 2048 * (1544 + 44) + 16 * 256
+    assert lib.lapwarm_lapjv_workspace_bytes(1, 0) == 0
     assert b"gfx950" in lib.lapwarm_build_info()
 
 
