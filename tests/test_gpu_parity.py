@@ -876,3 +876,29 @@ def test_cold_integer_costs_with_lists_repeatable(torch_cuda):
             assert r == int(ret[b]) == 0, (rep, b, int(ret[b]), st[b, 12])
             assert np.array_equal(xo, x[b].cpu().numpy()) and np.array_equal(yo, y[b].cpu().numpy()), (rep, b)
             assert st[b, 11] == so["arr_iters"] and st[b, 4] == so["paths"] and st[b, 27] > 0
+
+
+@pytest.mark.parametrize("n,fam", [(513, "int100"), (600, "tie"), (4608, "uniform")])
+def test_cold_lists_at_boundary_and_cooperative_sizes(torch_cuda, n, fam):
+    """Cold `lapjv` with candidate lists at the first sizes that use them (n = 513: the last column class
+    holds one element; n = 600: not a multiple of 64) and above the cooperative threshold (n = 4608:
+    preparation with lists, cooperative shortest paths, final phase -- three kinds of launches).  Bit-exact."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    from oracle import jv
+    from solvers.generators import mixed_batch
+    if fam == "int100":
+        C0 = np.random.RandomState(9).randint(1, 101, (n, n)).astype(np.float64)
+    elif fam == "uniform":
+        C0 = np.random.RandomState(9).uniform(0, 1, (n, n))
+    else:
+        C0 = mixed_batch(1, n, families=(fam,), seed=9)[0][0]
+    pipe = WarmStartPipeline(OneGNN(21), "cuda:0")
+    x, y, ret, st = pipe.lapjv_batch(torch.from_numpy(C0).cuda().unsqueeze(0))
+    torch.cuda.synchronize()
+    st = st.cpu().numpy()
+    r, xo, yo, so = jv.dense_raw(C0)
+    assert r == int(ret[0]) == 0, st[0, 12]
+    assert np.array_equal(xo, x[0].cpu().numpy()) and np.array_equal(yo, y[0].cpu().numpy())
+    assert st[0, 11] == so["arr_iters"] and st[0, 4] == so["paths"] and st[0, 6] == so["scan_steps"]
+    assert st[0, 27] > 0  # the lists were used
