@@ -75,12 +75,18 @@ int lapwarm_warmstart_lapjv(const double *C, int n, const double *u, const doubl
  * 2 free rows, 3 micro-ARR firings, 4 paths, 5 minima collections, 6 relax steps,
  * 7 relax elements (sum of n-hi), 8 path-init elements, 9 column-reduction elements,
  * 10 reduction-transfer rows, 11 ARR iterations, 12 internal error bits, 13 kernel time and
- * 14 greedy+micro-ARR time (10 ns ticks); 16..31 cycle stamps, only in -DLAPWARM_STAMPS builds. */
+ * 14 greedy+micro-ARR time (10 ns ticks); 15 paths completed by the cooperative kernel | stop reason << 32
+ * (-1: that kernel was not part of the solve); 16..26 its exchange-round counters; 27 row-reduction
+ * iterations answered from candidate lists (cold solves); 16..31 cycle stamps in -DLAPWARM_STAMPS builds.
+ * Where a solve consists of several launches (n >= 4428, cold solves with lists) slot 13 adds up the
+ * preparation launch and the final one. */
 
 size_t lapwarm_seeded_workspace_bytes(int batch, int n);
 /* Workspace of the cold entry points below: the seeded workspace plus, from n = 512, the candidate lists
- * of the augmenting row reduction (1,544 bytes per row).  A workspace of only
- * lapwarm_seeded_workspace_bytes() is accepted too; every row-reduction iteration then scans its row. */
+ * of the augmenting row reduction (1,544 bytes per row) and the hand-over state of the two launches a cold
+ * solve then consists of (preparation with the lists, shortest augmenting paths; 44 bytes per row).  A
+ * workspace of only lapwarm_seeded_workspace_bytes() is accepted too: one launch, every row-reduction
+ * iteration scans its row (LAP/_lapjv_cpp/lapjv.cpp:76-149 as written). */
 size_t lapwarm_lapjv_workspace_bytes(int batch, int n);
 
 /* Batched lapjv_seeded over C[batch][n][n]; u_seed, v_seed [batch][n]; x, y [batch][n] int64;
