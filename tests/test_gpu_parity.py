@@ -878,7 +878,7 @@ def test_cold_integer_costs_with_lists_repeatable(torch_cuda):
             assert st[b, 11] == so["arr_iters"] and st[b, 4] == so["paths"] and st[b, 27] > 0
 
 
-@pytest.mark.parametrize("n,fam", [(513, "int100"), (600, "tie"), (4608, "uniform")])
+@pytest.mark.parametrize("n,fam", [(513, "int100"), (600, "tie"), (4608, "uniform"), (8192, "uniform")])
 def test_cold_lists_at_boundary_and_cooperative_sizes(torch_cuda, n, fam):
     """Cold `lapjv` with candidate lists at the first sizes that use them (n = 513: the last column class
     holds one element; n = 600: not a multiple of 64) and above the cooperative threshold (n = 4608:
@@ -902,3 +902,25 @@ def test_cold_lists_at_boundary_and_cooperative_sizes(torch_cuda, n, fam):
     assert np.array_equal(xo, x[0].cpu().numpy()) and np.array_equal(yo, y[0].cpu().numpy())
     assert st[0, 11] == so["arr_iters"] and st[0, 4] == so["paths"] and st[0, 6] == so["scan_steps"]
     assert st[0, 27] > 0  # the lists were used
+
+
+def test_quality_gate_fallback_at_a_cooperative_size(torch_cuda):
+    """Seeds without a single tight edge at n = 4608: the preparation launch takes the cold branch (column
+    reduction + row reduction with plain scans -- the seeded launches carry no candidate lists), the
+    cooperative kernel searches the paths, the final launch writes the outputs.  Bit-exact, branch 3."""
+    torch = torch_cuda
+    from gnn import OneGNN, WarmStartPipeline
+    from oracle import jv
+    n = 4608
+    C0 = np.random.RandomState(21).uniform(0.5, 1.5, (n, n))
+    C = torch.from_numpy(C0).cuda().unsqueeze(0)
+    u = torch.zeros((1, n), dtype=torch.float64, device="cuda")
+    v = torch.zeros((1, n), dtype=torch.float64, device="cuda")
+    pipe = WarmStartPipeline(OneGNN(21), "cuda:0")
+    x, y, ret, stats = pipe.seeded_batch(C, u, v)
+    torch.cuda.synchronize()
+    st = stats.cpu().numpy()
+    r, xo, yo, so = jv.seeded_raw(C0, np.zeros(n), np.zeros(n))
+    assert r == int(ret[0]) == 0, st[0, 12]
+    assert np.array_equal(xo, x[0].cpu().numpy()) and np.array_equal(yo, y[0].cpu().numpy())
+    assert st[0, 0] == so["branch"] == 3 and st[0, 11] == so["arr_iters"] and st[0, 4] == so["paths"]
