@@ -1383,11 +1383,10 @@ struct Solver {
         // a NaN in column 0 poisons the serial scan's running minimum (lapjv.cpp:87-104): such a row
         // always takes the full scan, which reproduces that
         if (__ballot(nan0)) tau = -pos_inf();
-        const size_t o = (size_t)i * kArrListLen + lane;
-        lcol[o] = j0;
-        lval[o] = r0;
-        lcol[o + kWave] = j1;
-        lval[o + kWave] = r1;
+        // the two entries of a lane sit side by side: one 16-byte and one 8-byte load per lane and iteration
+        const size_t o = (size_t)i * kArrListLen + 2 * lane;
+        *reinterpret_cast<double2 *>(lval + o) = make_double2(r0, r1);
+        *reinterpret_cast<int2 *>(lcol + o) = make_int2(j0, j1);
         if (lane == 0) ltau[i] = tau;
     }
 
@@ -1635,6 +1634,17 @@ struct Solver {
         return new_free;
     }
 
+    // wave minimum of values that are never NaN (the list keys below): one v_min_f64 per step instead of a
+    // compare and two selects (as inline asm it would also lose the canonicalising v_max in front, but the
+    // hazard recogniser does not see an asm's result feeding the next DPP move)
+    __device__ __forceinline__ static double wave_min_nn(double x)
+    {
+#define LAPWARM_STEP(C, M) x = __builtin_fmin(x, dpp_move<C, M>(pos_inf(), x));
+        LAPWARM_DPP_REDUCE(LAPWARM_STEP)
+#undef LAPWARM_STEP
+        return readlane_f64(x, kWave - 1);
+    }
+
     // The same sweep with the candidate lists in front of the row scans.
     template <bool LISTS>
     __device__ __forceinline__ int cold_arr_sweep(int n_free, double *lval, int *lcol, double *ltau)
@@ -1666,12 +1676,20 @@ struct Solver {
                     // that row was known (before the second minimum and the updates)
                     int cand = -1, pca = -1, pcb = -1;
                     double pra = 0.0, prb = 0.0, ptau = 0.0;
-                    while (current < (unsigned)n_free) {
-                        const int free_i = (fwd >= 0) ? fwd : fr[current];
+                    // The loop state in SCALAR registers (readfirstlane): the compiler cannot know that a value
+                    // computed by every lane of this wave alike is uniform, and would steer every branch of
+                    // the iteration through the exec mask (~60 of its ~330 instructions).
+                    unsigned cur_s = (unsigned)uni((int)current), rr_s = (unsigned)uni((int)rr);
+                    int nf_s = uni(new_free), fwd_s = uni(fwd), it_s = uni(arr_iters), fast_s = uni(n_fast);
+                    const unsigned nfree_s = (unsigned)uni(n_free), un_s = (unsigned)uni(n);
+                    while (cur_s < nfree_s) {
+                        const int free_i = (fwd_s >= 0) ? fwd_s : uni(fr[cur_s]);
                         if (free_i != cand) {
-                            const size_t o = (size_t)free_i * kArrListLen + lane;
-                            pca = lcol[o], pcb = lcol[o + kWave];
-                            pra = lval[o], prb = lval[o + kWave];
+                            const size_t o = (size_t)free_i * kArrListLen + 2 * lane;
+                            const double2 rv = *reinterpret_cast<const double2 *>(lval + o);
+                            const int2 cv = *reinterpret_cast<const int2 *>(lcol + o);
+                            pca = cv.x, pcb = cv.y;
+                            pra = rv.x, prb = rv.y;
                             ptau = ltau[free_i];
                         }
                         const int ca = pca, cb = pcb;
@@ -1692,7 +1710,7 @@ struct Solver {
                         const double k1 = (l1 == l1) ? l1 : pos_inf(), k2 = (l2 == l2) ? l2 : pos_inf();
                         // smallest (value, column) pair: the value by a DPP reduction; the column needs a
                         // second reduction only when several lanes hold that value
-                        const double m1 = wave_min(k1);
+                        const double m1 = wave_min_nn(k1);
                         unsigned long long b1 = __ballot(k1 == m1 && i1 >= 0);
                         int g1 = 0x7fffffff;
                         if (__popcll(b1) == 1) {
@@ -1704,17 +1722,19 @@ struct Solver {
                         const bool win = (k1 == m1) && (i1 == g1);
                         if (b1) {
                             const int i0s = __builtin_amdgcn_readlane(y1, __builtin_ctzll(b1));
-                            if ((unsigned)i0s < un) {
+                            if ((unsigned)i0s < un_s) {
                                 cand = i0s;
-                                const size_t o = (size_t)i0s * kArrListLen + lane;
-                                pca = lcol[o], pcb = lcol[o + kWave];
-                                pra = lval[o], prb = lval[o + kWave];
+                                const size_t o = (size_t)i0s * kArrListLen + 2 * lane;
+                                const double2 rv = *reinterpret_cast<const double2 *>(lval + o);
+                                const int2 cv = *reinterpret_cast<const int2 *>(lcol + o);
+                                pca = cv.x, pcb = cv.y;
+                                pra = rv.x, prb = rv.y;
                                 ptau = ltau[i0s];
                             }
                         }
                         const double s2 = win ? k2 : k1;
                         const int si = win ? i2 : i1, sy = win ? y2 : y1;
-                        const double m2 = wave_min(s2);
+                        const double m2 = wave_min_nn(s2);
                         unsigned long long b2 = __ballot(s2 == m2 && si >= 0);
                         int g2 = 0x7fffffff;
                         if (__popcll(b2) == 1) {
@@ -1724,51 +1744,62 @@ struct Solver {
                             b2 = __ballot(s2 == m2 && si == g2);
                         }
                         const bool ok = (m2 < tau) && (m2 < kLarge) && (m1 > -kLarge) && g1 != 0x7fffffff && g2 != 0x7fffffff;
-                        if (!ok) break;  // (uniform) this row takes the full scan; nothing was changed
+                        if (__ballot(!ok)) break;  // (uniform) this row takes the full scan; nothing was changed
                         const int ln1 = __builtin_ctzll(b1), ln2 = __builtin_ctzll(b2);
                         const double vj1 = readlane_f64(w1, ln1);
                         int i0 = __builtin_amdgcn_readlane(y1, ln1);
                         const int i0_second = __builtin_amdgcn_readlane(sy, ln2);
                         int j1 = g1;
                         const int j2 = g2;
-                        rr++;
-                        current++;
-                        fwd = -1;
-                        arr_iters++;
-                        n_fast++;
+                        rr_s++;
+                        cur_s++;
+                        fwd_s = -1;
+                        it_s++;
+                        fast_s++;
                         const double v1_new = vj1 - (m2 - m1);
-                        const bool lowers = v1_new < vj1;
-                        if (rr < current * un) {
+                        const bool lowers = __ballot(v1_new < vj1) != 0ull;  // (a scalar condition)
+                        // the decisions first (uniform), then ONE masked block with every store of the iteration
+                        bool store_v = false;
+                        int fr_at = -1;
+                        if (rr_s < cur_s * un_s) {
                             if (lowers) {
-                                if (lane == 0) v[j1] = v1_new;
+                                store_v = true;
                             } else if (i0 >= 0) {
                                 j1 = j2;
                                 i0 = i0_second;
                             }
                             if (i0 >= 0) {
                                 if (lowers) {
-                                    --current;
-                                    fwd = i0;
-                                    if (lane == 0) fr[current] = i0;
+                                    --cur_s;
+                                    fwd_s = i0;
+                                    fr_at = (int)cur_s;
                                 } else {
-                                    if (lane == 0) fr[new_free] = i0;
-                                    ++new_free;
+                                    fr_at = nf_s;
+                                    ++nf_s;
                                 }
                             }
                         } else if (i0 >= 0) {
-                            if (lane == 0) fr[new_free] = i0;
-                            ++new_free;
+                            fr_at = nf_s;
+                            ++nf_s;
                         }
                         if (lane == 0) {
+                            if (store_v) v[g1] = v1_new;
+                            if (fr_at >= 0) fr[fr_at] = i0;
                             x[free_i] = j1;
                             y[j1] = free_i;
                         }
                         fence_if_global();  // (state in global memory: the next iteration's lanes read these)
-                        if (arr_iters > (1 << 26)) {
+                        if (it_s > (1 << 26)) {
                             bad = 4;
                             break;
                         }
                     }
+                    current = cur_s;
+                    rr = rr_s;
+                    new_free = nf_s;
+                    fwd = fwd_s;
+                    arr_iters = it_s;
+                    n_fast = fast_s;
                     if (lane == 0) {
                         as->arr_current = current;
                         as->arr_rr = rr;
