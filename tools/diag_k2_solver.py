@@ -1,4 +1,9 @@
-import sys; sys.path[:0] = ["/root/repo", "/root/repo/gnn-accelerated-lap-warm-start-pipeline_amd"]
+"""K2-shaped solver launch (64 x 512, optimal duals + min-trick as seeds): wall time, kernel ticks, the serial
+(greedy + micro-ARR) part, branches and paths (diagnostic)."""
+import sys
+from pathlib import Path
+ROOT = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(ROOT), str(ROOT / "gnn-accelerated-lap-warm-start-pipeline_amd")]
 import numpy as np, torch, time
 from gnn import OneGNN, WarmStartPipeline
 from gnn.features import min_trick_device
